@@ -1,0 +1,150 @@
+/*
+ * isingmc.h -- C ABI of libisingmc.so, the MI355X (gfx950) classical Ising Metropolis engine.
+ *
+ * This is the drop-in boundary for the hot path of Renmusxd/PyIsingMonteCarlo: the reference's
+ * pyo3 shell (src/lattice.rs, src/classicising.rs) drives one `qmc::classical::graph::GraphState`
+ * per experiment from a rayon loop; a maintainer replaces that loop with the calls below
+ * (INTEGRATION.md shows the `extern "C"` block).  Each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only; the caller owns every host buffer; the
+ * handles own all device memory.  Every function returns ISINGMC_OK or an error code and never
+ * aborts the process (the reference aborts on engine errors: lattice.rs:206 + Cargo.toml:14);
+ * isingmc_last_error() returns the message of the calling thread's last failure.
+ *
+ * There is NO CPU fallback: without a usable HIP device every device entry point fails with
+ * ISINGMC_ERR_NO_DEVICE.  The isingmc_host_* helpers are pure host code and need no device.
+ *
+ * Hamiltonian: E = sum_edges J_ab s_a s_b - sum_i h_i s_i, s = +1 for True (README.md:45-46;
+ * bias sign [UNVERIFIED]).
+ */
+#ifndef ISINGMC_H
+#define ISINGMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISINGMC_ABI_VERSION 1
+
+enum {
+    ISINGMC_OK = 0,
+    ISINGMC_ERR_INVALID = 1,   /* bad argument: maps to Python ValueError */
+    ISINGMC_ERR_NO_DEVICE = 2, /* no HIP device / bad ordinal: RuntimeError */
+    ISINGMC_ERR_HIP = 3,       /* a HIP runtime call failed: RuntimeError */
+    ISINGMC_ERR_ALLOC = 4      /* host or device allocation failed: MemoryError */
+};
+
+/* graph kinds reported by isingmc_graph_info */
+enum {
+    ISINGMC_KIND_GENERAL = 0,  /* greedy-coloured CSR path, any edge list */
+    ISINGMC_KIND_LATTICE2D = 1 /* periodic W x H square lattice, uniform |J|: checkerboard path */
+};
+
+/* isingmc_graph_create flags */
+#define ISINGMC_FLAG_FORCE_GENERAL 1u /* skip the lattice recogniser (BASELINE config c5) */
+
+typedef struct isingmc_graph isingmc_graph;   /* edges + biases: the per-experiment adjacency that
+                                                 GraphState::new builds (lattice.rs:199), built once */
+typedef struct isingmc_states isingmc_states; /* R replicas = R x GraphState<SmallRng> on one device */
+
+typedef struct {
+    int32_t kind;        /* ISINGMC_KIND_* */
+    int32_t device;      /* HIP device ordinal */
+    uint64_t nvars;      /* max index + 1 (lattice.rs:51-55) */
+    uint64_t n_edges;
+    int32_t width;       /* LATTICE2D: W (columns), else 0 */
+    int32_t height;      /* LATTICE2D: H (rows), else 0 */
+    double jabs;         /* LATTICE2D: the common |J| */
+    int32_t uniform_sign;/* LATTICE2D: 1 if every bond has the same sign */
+    uint32_t n_colours;  /* independent sets per timestep (2 on the lattice path) */
+    uint64_t state_words;/* 32-bit words of packed spin state per replica */
+} isingmc_graph_info_t;
+
+const char *isingmc_last_error(void);
+int isingmc_abi_version(void);
+int isingmc_device_count(int *count);
+
+/* ---- host-only helpers (no device) ------------------------------------------------------ */
+
+/* lattice.rs:83-91 make_seeds: master SmallRng (seed_from_u64(seed_gen), or OS entropy when
+ * has_seed == 0) -> one u64 per experiment. */
+int isingmc_host_make_seeds(int has_seed, uint64_t seed_gen, size_t n, uint64_t *seeds_out);
+
+/* lattice.rs:320-334 + 358-365 (and 406-420 + 445-451): sort the (t, beta) stops, default
+ * [(0,1),(T,1)], pad to [0,T], and expand to one beta per timestep by linear interpolation.
+ * compat_constant_beta != 0 reproduces the reference's behaviour (the interpolation index is a
+ * captured constant, so beta is the last stop's beta for the whole run). */
+int isingmc_host_expand_schedule(const uint64_t *stop_t, const double *stop_beta, size_t n_stops,
+                                 size_t timesteps, int compat_constant_beta, double *betas_out);
+
+/* Recogniser: is this edge list a periodic W x H square lattice with ids y*W+x, every bond
+ * present once, uniform |J|?  *is_lattice = 0 when not (then the general path is used). */
+int isingmc_host_recognise_lattice2d(const uint64_t *edge_a, const uint64_t *edge_b,
+                                     const double *edge_j, size_t n_edges, size_t nvars,
+                                     int *is_lattice, int *width, int *height, double *jabs,
+                                     int *uniform_sign);
+
+/* Greedy colouring used by the general path (sites in index order, smallest free colour). */
+int isingmc_host_colour_graph(const uint64_t *edge_a, const uint64_t *edge_b, size_t n_edges,
+                              size_t nvars, uint32_t *colours_out, uint32_t *n_colours_out);
+
+/* ---- graph: replaces the adjacency half of GraphState::new (lattice.rs:199, classicising.rs:73)
+ * edges as three parallel arrays (the Vec<((usize,usize),f64)> of lattice.rs:47); biases NULL
+ * (all zero) or nvars doubles (lattice.rs:186-189).  device = HIP ordinal. */
+int isingmc_graph_create(const uint64_t *edge_a, const uint64_t *edge_b, const double *edge_j,
+                         size_t n_edges, size_t nvars, const double *biases, int device,
+                         unsigned flags, isingmc_graph **graph_out);
+int isingmc_graph_info(const isingmc_graph *graph, isingmc_graph_info_t *info_out);
+void isingmc_graph_destroy(isingmc_graph *graph);
+
+/* ---- states: replaces R x { SmallRng::seed_from_u64(seed); GraphState::new(..., rng);
+ * set_state(initial) } (lattice.rs:198-203) and GraphState::new_with_state_and_rng
+ * (classicising.rs:71).  seeds[r] keys replica r's Philox stream (results do not depend on which
+ * device or in which batch a replica runs).  initial_state: NULL (random start) or nvars bytes
+ * (nonzero = True) copied into every replica.  The graph must outlive the states. */
+int isingmc_states_create(isingmc_graph *graph, size_t n_replicas, const uint64_t *seeds,
+                          const uint8_t *initial_state, isingmc_states **states_out);
+/* ClassicIsing.add_graph (classicising.rs:62-79): append one replica. */
+int isingmc_states_append(isingmc_states *states, uint64_t seed, const uint8_t *initial_state);
+/* GraphState::set_state (lattice.rs:202) on one replica. */
+int isingmc_states_set_state(isingmc_states *states, size_t replica, const uint8_t *state);
+size_t isingmc_states_count(const isingmc_states *states);
+void isingmc_states_destroy(isingmc_states *states);
+
+/* Per-replica inverse temperatures (parallel-tempering ladder; shaped after
+ * LatticeTempering.add_graph(beta), tempering.rs:70-113).  NULL clears them.  While set, the
+ * betas argument of isingmc_do_time_steps is ignored. */
+int isingmc_states_set_betas(isingmc_states *states, const double *beta_per_replica);
+
+/* replaces `for _ in 0..timesteps { gs.do_time_step(beta, None, None, None, only_basic) }`
+ * (lattice.rs:204-207, 271-280, 358-368, 445-455; classicising.rs:97-109) for all replicas.
+ * One timestep = one full sweep = nvars single-spin Metropolis attempts per replica.
+ * Timestep k uses beta = betas[k * beta_stride] (stride 0: constant beta).
+ * energies_per_step: NULL, or double[R][timesteps] receiving get_energy() after every timestep
+ * (lattice.rs:454).  Blocking: returns after the device has finished. */
+int isingmc_do_time_steps(isingmc_states *states, size_t timesteps, const double *betas,
+                          size_t beta_stride, double *energies_per_step);
+/* Same work, additionally reporting the device time of the sweep kernels (HIP events recorded on
+ * the engine's stream around the launches) -- the measurement hook of bench.py. */
+int isingmc_do_time_steps_timed(isingmc_states *states, size_t timesteps, const double *betas,
+                                size_t beta_stride, float *device_ms_out);
+
+/* GraphState::get_energy (lattice.rs:208, 284, 370; classicising.rs:171): double[R]. */
+int isingmc_get_energies(isingmc_states *states, double *energies_out);
+/* sum_i s_i per replica: int64[R] (the build's own observable for <|M|> parity). */
+int isingmc_get_magnetisations(isingmc_states *states, int64_t *mags_out);
+/* GraphState::get_state / state_ref (lattice.rs:209-211, 281-283): replica r's nvars spins as
+ * bytes (1 = True) at states_out + r * replica_stride_bytes (stride >= nvars; lets the caller
+ * write straight into a bool[R,S,N] array). */
+int isingmc_get_states(isingmc_states *states, uint8_t *states_out, size_t replica_stride_bytes);
+/* Raw packed device words of every replica (layout: DESIGN.md S2), uint32[R][state_words]. */
+int isingmc_get_packed_states(isingmc_states *states, uint32_t *words_out);
+/* Absolute timestep counter of the replicas (Philox counter word; persists across calls). */
+uint64_t isingmc_states_timestep(const isingmc_states *states);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISINGMC_H */

@@ -1,0 +1,621 @@
+/*
+ * ising_oracle.c -- CPU ORACLE for the classical Ising Metropolis hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker.  The product path (pyisingmontecarlo_amd/, libisingmc.so) never links, imports
+ * or falls back to it.
+ *
+ * PARITY UNPINNED against the reference's arithmetic: the reference
+ * (/root/reference/src/lattice.rs:171-470, src/classicising.rs:62-179) delegates every
+ * Metropolis operation to the third-party crate `qmc ^2.20` (Cargo.toml:23-25), whose source is
+ * not in the tree, and ships no tests or golden vectors; no Rust toolchain exists here.  What
+ * pins this oracle instead: Random123's published Philox4x32-10 known-answer vectors, the
+ * xoshiro256++ reference vector, the README's Hamiltonian (README.md:45-46, energy = J*Sza*Szb,
+ * positive J antiferromagnetic) on hand-checkable states, exact enumeration on small graphs and
+ * Kaufman's exact finite-torus solution (oracle/exact.py, tests/).
+ *
+ * Three engines live here:
+ *
+ *  A. orc_ref_*   "reference-faithful" restatement of what lattice.rs:192-212 drives: one
+ *                 replica = one sequential chain; adjacency list; one bool per spin; f64 dE;
+ *                 a timestep = nvars single-spin Metropolis attempts at uniformly random sites,
+ *                 accept if dE <= 0 else with probability exp(-beta dE); per-replica
+ *                 xoshiro256++ (rand 0.8 SmallRng on 64-bit targets) seeded from the u64 that
+ *                 make_seeds (lattice.rs:83-91) hands out.  The crate-internal details
+ *                 (order of rng draws, edge/worm moves) are [UNVERIFIED] recollection; this
+ *                 engine is the timed CPU baseline and a statistical cross-check, never a
+ *                 bit-level authority.
+ *
+ *  B. orc_lat_*   serial, per-spin restatement of the build's own 2-colour checkerboard
+ *                 algorithm on a periodic W x H square lattice with uniform |J| (DESIGN.md
+ *                 "Algorithm specification", S3).  Same Philox counters, same 40-bit
+ *                 acceptance thresholds => the HIP kernels must reproduce its spin
+ *                 configurations BIT FOR BIT.  Written spin-by-spin (no bit-slicing) on purpose,
+ *                 so that it checks the kernel's bit-sliced logic independently.
+ *
+ *  C. orc_gen_*   serial restatement of the general edge-list path (greedy colouring,
+ *                 f64 local fields, deterministic exp), DESIGN.md S4.  Also bit-exact.
+ *
+ * Hamiltonian (all engines):  E = sum_edges J_ab s_a s_b  -  sum_i h_i s_i,  s = +1 for True.
+ * The edge term follows README.md:45-46; the sign of the bias term is [UNVERIFIED]
+ * (crate-internal), chosen as -h s.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DOM_LAT_SWEEP 0x4C415453u /* "LATS" */
+#define DOM_LAT_INIT 0x4C415449u  /* "LATI" */
+#define DOM_GEN_SWEEP 0x47454E53u /* "GENS" */
+#define DOM_GEN_INIT 0x47454E49u  /* "GENI" */
+#define DOM_PT_SWAP 0x50545357u   /* "PTSW" */
+
+#define N_PLANES 8 /* bit-planes of the acceptance uniform drawn before the residual stage */
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123).  Pinned by the Random123
+ * known-answer vectors in tests/golden/philox_kat.json.
+ * ---------------------------------------------------------------------------------------- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void philox_seeded(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                          uint32_t out[4])
+{
+    uint32_t ctr[4] = {c0, c1, c2, c3};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    orc_philox4x32_10(ctr, key, out);
+}
+
+/* counter word 2: (t >> 32) in the top 16 bits, colour in bits 8..15, call index in bits 0..7 */
+static uint32_t ctr2(uint64_t t, uint32_t colour, uint32_t call)
+{
+    return (uint32_t)(((t >> 32) & 0xFFFFu) << 16) | ((colour & 0xFFu) << 8) | (call & 0xFFu);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * xoshiro256++ with SplitMix64 seeding = rand 0.8 `SmallRng::seed_from_u64` on 64-bit targets
+ * (published algorithm; the rand crate itself is not in the tree => [UNVERIFIED] that the
+ * reference's Cargo resolution picks exactly this generator).  Used by make_seeds
+ * (lattice.rs:83-91) and by the reference-faithful engine (lattice.rs:198).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint64_t s[4]; } xoshiro;
+
+static uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static uint64_t xo_next(xoshiro *g)
+{
+    uint64_t *s = g->s;
+    uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+static void xo_seed_from_u64(xoshiro *g, uint64_t state)
+{
+    for (int i = 0; i < 4; i++) {
+        state += 0x9e3779b97f4a7c15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        g->s[i] = z ^ (z >> 31);
+    }
+}
+
+/* raw generator from an explicit state: for the xoshiro256++ reference vector */
+void orc_xoshiro_from_state(const uint64_t s[4], size_t n, uint64_t *out)
+{
+    xoshiro g;
+    memcpy(g.s, s, sizeof g.s);
+    for (size_t i = 0; i < n; i++) out[i] = xo_next(&g);
+}
+
+/* lattice.rs:83-91: master rng seeded from seed_gen, one u64 per experiment */
+void orc_make_seeds(uint64_t seed_gen, size_t n, uint64_t *out)
+{
+    xoshiro g;
+    xo_seed_from_u64(&g, seed_gen);
+    for (size_t i = 0; i < n; i++) out[i] = xo_next(&g);
+}
+
+static double xo_f64(xoshiro *g) { return (double)(xo_next(g) >> 11) * (1.0 / 9007199254740992.0); }
+
+static int xo_bool(xoshiro *g) { return (int32_t)(uint32_t)(xo_next(g) >> 32) < 0; }
+
+/* rand 0.8 UniformInt::sample_single for u64 ranges [0, range) (widening-multiply rejection) */
+static uint64_t xo_below(xoshiro *g, uint64_t range)
+{
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    for (;;) {
+        unsigned __int128 m = (unsigned __int128)xo_next(g) * range;
+        if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Energy of an explicit configuration: E = sum J s_a s_b - sum h s   (README.md:45-46).
+ * state: one byte per spin, nonzero = True = +1.
+ * ---------------------------------------------------------------------------------------- */
+double orc_energy(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                  size_t nvars, const double *biases, const uint8_t *state)
+{
+    double e = 0.0;
+    for (size_t k = 0; k < n_edges; k++) {
+        int sa = state[ea[k]] ? 1 : -1, sb = state[eb[k]] ? 1 : -1;
+        e += ej[k] * (double)(sa * sb);
+    }
+    if (biases)
+        for (size_t i = 0; i < nvars; i++) e -= biases[i] * (state[i] ? 1.0 : -1.0);
+    return e;
+}
+
+/* ==========================================================================================
+ * A. reference-faithful engine
+ * ======================================================================================== */
+typedef struct {
+    size_t nvars;
+    size_t *ptr;     /* CSR row pointers, nvars+1 */
+    uint32_t *nbr;   /* neighbour ids */
+    double *w;       /* couplings */
+} adjacency;
+
+static void adj_build(adjacency *A, size_t n_edges, const uint64_t *ea, const uint64_t *eb,
+                      const double *ej, size_t nvars)
+{
+    A->nvars = nvars;
+    A->ptr = calloc(nvars + 1, sizeof(size_t));
+    for (size_t k = 0; k < n_edges; k++)
+        if (ea[k] != eb[k]) { A->ptr[ea[k] + 1]++; A->ptr[eb[k] + 1]++; }
+    for (size_t i = 0; i < nvars; i++) A->ptr[i + 1] += A->ptr[i];
+    size_t nnz = A->ptr[nvars];
+    A->nbr = malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+    A->w = malloc((nnz ? nnz : 1) * sizeof(double));
+    size_t *fill = malloc((nvars + 1) * sizeof(size_t));
+    memcpy(fill, A->ptr, (nvars + 1) * sizeof(size_t));
+    for (size_t k = 0; k < n_edges; k++) { /* neighbours of i appear in edge-list order */
+        if (ea[k] == eb[k]) continue;
+        A->nbr[fill[ea[k]]] = (uint32_t)eb[k]; A->w[fill[ea[k]]++] = ej[k];
+        A->nbr[fill[eb[k]]] = (uint32_t)ea[k]; A->w[fill[eb[k]]++] = ej[k];
+    }
+    free(fill);
+}
+
+static void adj_free(adjacency *A) { free(A->ptr); free(A->nbr); free(A->w); }
+
+/*
+ * One experiment of Lattice::run_monte_carlo (lattice.rs:197-212): seed -> rng, random initial
+ * state unless `initial` is given, `timesteps` x do_time_step(beta), then energy + state.
+ * betas: per-timestep beta (length timesteps) so that the annealing variants
+ * (lattice.rs:358-368) can reuse it; energies_per_step may be NULL (lattice.rs:445-455).
+ */
+static void ref_run_one(const adjacency *A, const double *biases, uint64_t seed,
+                        const uint8_t *initial, const double *betas, size_t timesteps,
+                        uint8_t *state, double *energy_out, double *energies_per_step,
+                        size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej)
+{
+    size_t n = A->nvars;
+    xoshiro g;
+    xo_seed_from_u64(&g, seed);
+    if (initial) memcpy(state, initial, n);
+    else for (size_t i = 0; i < n; i++) state[i] = (uint8_t)xo_bool(&g);
+    for (size_t t = 0; t < timesteps; t++) {
+        double beta = betas[t];
+        for (size_t a = 0; a < n; a++) {
+            size_t i = (size_t)xo_below(&g, n);
+            double si = state[i] ? 1.0 : -1.0;
+            double field = 0.0;
+            for (size_t e = A->ptr[i]; e < A->ptr[i + 1]; e++)
+                field += A->w[e] * (state[A->nbr[e]] ? 1.0 : -1.0);
+            double dE = 2.0 * si * ((biases ? biases[i] : 0.0) - field);
+            if (dE <= 0.0 || xo_f64(&g) < exp(-beta * dE)) state[i] = !state[i];
+        }
+        if (energies_per_step)
+            energies_per_step[t] = orc_energy(n_edges, ea, eb, ej, n, biases, state);
+    }
+    if (energy_out) *energy_out = orc_energy(n_edges, ea, eb, ej, n, biases, state);
+}
+
+/*
+ * R experiments, one per OpenMP thread (the rayon fan-out of lattice.rs:192-197).
+ * states_out: uint8[R][nvars]; energies_out: double[R]; energies_per_step: double[R][T] or NULL.
+ */
+void orc_ref_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                 size_t nvars, const double *biases, const uint64_t *seeds, size_t R,
+                 const uint8_t *initial, const double *betas, size_t timesteps,
+                 uint8_t *states_out, double *energies_out, double *energies_per_step)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t r = 0; r < R; r++)
+        ref_run_one(&A, biases, seeds[r], initial, betas, timesteps, states_out + r * nvars,
+                    energies_out ? energies_out + r : NULL,
+                    energies_per_step ? energies_per_step + r * timesteps : NULL, n_edges, ea, eb,
+                    ej);
+    adj_free(&A);
+}
+
+/* ==========================================================================================
+ * Acceptance threshold, 40-bit fixed point: accept iff u40 < T, u40 uniform on [0, 2^40).
+ * T = 2^40 (always) when dE <= 0 or exp(-beta dE) >= 1.
+ * ======================================================================================== */
+uint64_t orc_threshold40(double beta, double dE)
+{
+    const uint64_t ONE = (uint64_t)1 << 40;
+    if (dE <= 0.0) return ONE;
+    double p = exp(-beta * dE);
+    if (!(p < 1.0)) return ONE;
+    return (uint64_t)floor(p * 1099511627776.0);
+}
+
+/* ==========================================================================================
+ * B. checkerboard lattice engine (uniform |J|, per-bond sign), periodic W x H.
+ *
+ * Layout restated from DESIGN.md S2: colour c = (x+y)&1; the colour-c sites of row y are
+ * x = 2i + ((y+c)&1), i = 0..W/2-1; plane c stores row y as W/64 words, bit (i&31) of word
+ * y*(W/64) + (i>>5).  state = plane 0 followed by plane 1.  A quad = 4 consecutive words of a
+ * plane (row-major linear word index / 4).
+ * ======================================================================================== */
+typedef struct { int W, H, wpr; size_t wpp; } lat_geom;
+
+static lat_geom lat_make(int W, int H)
+{
+    lat_geom g = {W, H, W / 64, (size_t)H * (size_t)(W / 64)};
+    return g;
+}
+
+int orc_lat_supported(int W, int H)
+{
+    return W >= 64 && W % 64 == 0 && H >= 2 && H % 2 == 0 && ((size_t)H * (size_t)(W / 64)) % 4 == 0;
+}
+
+size_t orc_lat_state_words(int W, int H) { return 2 * lat_make(W, H).wpp; }
+
+static int lat_get(const lat_geom *g, const uint32_t *state, int y, int x)
+{
+    int c = (x + y) & 1, i = x >> 1;
+    return (state[(size_t)c * g->wpp + (size_t)y * g->wpr + (i >> 5)] >> (i & 31)) & 1;
+}
+
+/* S2: random initial state, word w of plane c = Philox(key, (w>>2, 0, c<<8, DOM_LAT_INIT))[w&3] */
+void orc_lat_init(int W, int H, uint64_t seed, uint32_t *state)
+{
+    lat_geom g = lat_make(W, H);
+    for (uint32_t c = 0; c < 2; c++)
+        for (size_t w = 0; w < g.wpp; w++) {
+            uint32_t r[4];
+            philox_seeded(seed, (uint32_t)(w >> 2), 0, ctr2(0, c, 0), DOM_LAT_INIT, r);
+            state[c * g.wpp + w] = r[w & 3];
+        }
+}
+
+void orc_lat_pack(int W, int H, const uint8_t *spins, uint32_t *state)
+{
+    lat_geom g = lat_make(W, H);
+    memset(state, 0, 2 * g.wpp * sizeof(uint32_t));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            if (spins[(size_t)y * W + x]) {
+                int c = (x + y) & 1, i = x >> 1;
+                state[(size_t)c * g.wpp + (size_t)y * g.wpr + (i >> 5)] |= 1u << (i & 31);
+            }
+}
+
+void orc_lat_unpack(int W, int H, const uint32_t *state, uint8_t *spins)
+{
+    lat_geom g = lat_make(W, H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) spins[(size_t)y * W + x] = (uint8_t)lat_get(&g, state, y, x);
+}
+
+/*
+ * Couplings: jabs = |J| of every bond; jright[y*W+x] / jdown[y*W+x] = 1 if the bond from
+ * (y,x) to (y,x+1) / (y+1,x) has J > 0 (antiferromagnetic), else 0.  NULL => uniform sign
+ * given by jpos_uniform.
+ */
+static int bond_pos(const uint8_t *plane, int jpos_uniform, int W, int y, int x)
+{
+    return plane ? plane[(size_t)y * W + x] : jpos_uniform;
+}
+
+/* number of satisfied bonds (J s s < 0) of site (y,x) */
+static int lat_satisfied(const lat_geom *g, const uint32_t *state, const uint8_t *jright,
+                         const uint8_t *jdown, int jpos_uniform, int y, int x)
+{
+    int W = g->W, H = g->H;
+    int s = lat_get(g, state, y, x);
+    int xl = (x + W - 1) % W, xr = (x + 1) % W, yu = (y + H - 1) % H, yd = (y + 1) % H;
+    int k = 0;
+    /* a bond with J>0 is satisfied when the spins differ, with J<0 when they agree */
+    k += (s != lat_get(g, state, y, xr)) == bond_pos(jright, jpos_uniform, W, y, x);
+    k += (s != lat_get(g, state, y, xl)) == bond_pos(jright, jpos_uniform, W, y, xl);
+    k += (s != lat_get(g, state, yd, x)) == bond_pos(jdown, jpos_uniform, W, y, x);
+    k += (s != lat_get(g, state, yu, x)) == bond_pos(jdown, jpos_uniform, W, yu, x);
+    return k;
+}
+
+/*
+ * S3: one timestep t = colour 0 pass then colour 1 pass.  Flipping a spin with k satisfied
+ * bonds costs dE = 2|J|(2k-4): k<=2 always flips, k=3 / k=4 flip iff u40 < T3 / T4 with
+ * u40 = (8-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only when
+ * the prefix equals the threshold's top 8 bits).
+ */
+void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                   const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)
+{
+    lat_geom g = lat_make(W, H);
+    uint64_t T3 = orc_threshold40(beta, 4.0 * jabs), T4 = orc_threshold40(beta, 8.0 * jabs);
+    size_t nquads = g.wpp / 4;
+    for (uint32_t c = 0; c < 2; c++) {
+        uint32_t *own = state + c * g.wpp;
+        for (size_t Q = 0; Q < nquads; Q++) {
+            uint32_t planes[N_PLANES][4];
+            for (uint32_t p = 0; p < N_PLANES; p++)
+                philox_seeded(seed, (uint32_t)Q, (uint32_t)t, ctr2(t, c, p), DOM_LAT_SWEEP,
+                              planes[p]);
+            uint32_t resid[4];
+            unsigned n_undecided = 0;
+            for (int q = 0; q < 4; q++) {
+                size_t w = 4 * Q + q;
+                int y = (int)(w / g.wpr), xw = (int)(w % g.wpr);
+                uint32_t flip = 0;
+                for (int b = 0; b < 32; b++) {
+                    int i = 32 * xw + b;
+                    int x = 2 * i + ((y + (int)c) & 1);
+                    int k = lat_satisfied(&g, state, jright, jdown, jpos_uniform, y, x);
+                    int accept;
+                    if (k <= 2) accept = 1;
+                    else {
+                        uint64_t T = (k == 3) ? T3 : T4;
+                        uint32_t hi = (uint32_t)(T >> 32), lo = (uint32_t)T;
+                        uint32_t u8 = 0;
+                        for (int p = 0; p < N_PLANES; p++)
+                            u8 = (u8 << 1) | ((planes[p][q] >> b) & 1u);
+                        if (u8 < hi) accept = 1;
+                        else if (u8 > hi) accept = 0;
+                        else {
+                            if ((n_undecided & 3) == 0)
+                                philox_seeded(seed, (uint32_t)Q, (uint32_t)t,
+                                              ctr2(t, c, N_PLANES + n_undecided / 4),
+                                              DOM_LAT_SWEEP, resid);
+                            accept = resid[n_undecided & 3] < lo;
+                            n_undecided++;
+                        }
+                    }
+                    flip |= (uint32_t)accept << b;
+                }
+                /* same-colour spins are never neighbours: in-place update is the simultaneous one */
+                own[w] ^= flip;
+            }
+        }
+    }
+}
+
+/* E = sum over bonds of J s s (J = +-jabs) and M = sum s, from the packed state */
+void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                        const uint8_t *jdown, const uint32_t *state, double *energy, int64_t *mag)
+{
+    lat_geom g = lat_make(W, H);
+    int64_t unsat_minus_sat = 0, m = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int s = lat_get(&g, state, y, x);
+            m += s ? 1 : -1;
+            int sr = lat_get(&g, state, y, (x + 1) % W), sd = lat_get(&g, state, (y + 1) % H, x);
+            unsat_minus_sat += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
+            unsat_minus_sat += ((s != sd) == bond_pos(jdown, jpos_uniform, W, y, x)) ? -1 : 1;
+        }
+    if (energy) *energy = jabs * (double)unsat_minus_sat;
+    if (mag) *mag = m;
+}
+
+/* ==========================================================================================
+ * C. general edge-list engine
+ * ======================================================================================== */
+
+/* deterministic exp for the acceptance test: IEEE f64 ops + fma only, so that gcc on x86 and
+ * hipcc on gfx950 produce identical bits.  Domain of use: x = -beta dE. */
+double orc_det_exp(double x)
+{
+    if (x >= 0.0) return 1.0;
+    if (x < -40.0) return 0.0; /* below 2^-53: can never beat a 53-bit uniform */
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    double kf = floor(fma(x, LOG2E, 0.5));
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    /* Taylor to degree 13 on |r| <= 0.35: truncation < 5e-18 */
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int64_t k = (int64_t)kf; /* in [-58, 0] */
+    uint64_t bits = (uint64_t)(1023 + k) << 52;
+    double scale;
+    memcpy(&scale, &bits, 8);
+    return p * scale;
+}
+
+/* greedy colouring in site order: smallest colour unused by already-coloured neighbours */
+typedef struct {
+    adjacency A;
+    uint32_t *colour;   /* per site */
+    uint32_t ncolours;
+    size_t *class_base; /* first packed position of each colour class, ncolours+1 */
+    size_t *pos;        /* site -> packed position (colour-major, classes padded to 64) */
+    size_t npos;
+} gen_graph;
+
+static void gen_build(gen_graph *G, size_t n_edges, const uint64_t *ea, const uint64_t *eb,
+                      const double *ej, size_t nvars)
+{
+    adj_build(&G->A, n_edges, ea, eb, ej, nvars);
+    G->colour = malloc(nvars * sizeof(uint32_t));
+    uint32_t nc = 1;
+    size_t maxdeg = 0;
+    for (size_t i = 0; i < nvars; i++)
+        if (G->A.ptr[i + 1] - G->A.ptr[i] > maxdeg) maxdeg = G->A.ptr[i + 1] - G->A.ptr[i];
+    uint8_t *used = calloc(maxdeg + 2, 1);
+    for (size_t i = 0; i < nvars; i++) {
+        size_t deg = G->A.ptr[i + 1] - G->A.ptr[i];
+        memset(used, 0, deg + 2);
+        for (size_t e = G->A.ptr[i]; e < G->A.ptr[i + 1]; e++) {
+            uint32_t j = G->A.nbr[e];
+            if (j < i && G->colour[j] <= deg) used[G->colour[j]] = 1;
+        }
+        uint32_t c = 0;
+        while (used[c]) c++;
+        G->colour[i] = c;
+        if (c + 1 > nc) nc = c + 1;
+    }
+    free(used);
+    G->ncolours = nc;
+    size_t *count = calloc(nc, sizeof(size_t));
+    for (size_t i = 0; i < nvars; i++) count[G->colour[i]]++;
+    G->class_base = malloc((nc + 1) * sizeof(size_t));
+    G->class_base[0] = 0;
+    for (uint32_t c = 0; c < nc; c++) G->class_base[c + 1] = G->class_base[c] + ((count[c] + 63) / 64) * 64;
+    G->npos = G->class_base[nc];
+    G->pos = malloc(nvars * sizeof(size_t));
+    memset(count, 0, nc * sizeof(size_t));
+    for (size_t i = 0; i < nvars; i++) G->pos[i] = G->class_base[G->colour[i]] + count[G->colour[i]]++;
+    free(count);
+}
+
+static void gen_free(gen_graph *G)
+{
+    adj_free(&G->A);
+    free(G->colour); free(G->class_base); free(G->pos);
+}
+
+/* expose the colouring for host-logic tests: colours[nvars], returns the number of colours */
+uint32_t orc_gen_colouring(size_t n_edges, const uint64_t *ea, const uint64_t *eb,
+                           const double *ej, size_t nvars, uint32_t *colours, uint64_t *positions)
+{
+    gen_graph G;
+    gen_build(&G, n_edges, ea, eb, ej, nvars);
+    for (size_t i = 0; i < nvars; i++) {
+        if (colours) colours[i] = G.colour[i];
+        if (positions) positions[i] = G.pos[i];
+    }
+    uint32_t nc = G.ncolours;
+    gen_free(&G);
+    return nc;
+}
+
+/*
+ * One experiment on the general path.  state: one byte per spin in SITE order.
+ * initial == NULL: S2' random start -- packed word w (positions 32w..32w+31) =
+ * Philox(key, (w>>2, 0, 0, DOM_GEN_INIT))[w&3]; site i takes bit pos(i)&31 of word pos(i)>>5.
+ * Timestep t (absolute, t0 + local index): colour classes in order; site i draws
+ * Philox(key, (i>>1, t_lo, t_hi16<<16, DOM_GEN_SWEEP)) words 2(i&1), 2(i&1)+1 -> 53-bit u.
+ */
+void orc_gen_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                 size_t nvars, const double *biases, uint64_t seed, const uint8_t *initial,
+                 uint64_t t0, const double *betas, size_t timesteps, uint8_t *state,
+                 double *energy_out, double *energies_per_step)
+{
+    gen_graph G;
+    gen_build(&G, n_edges, ea, eb, ej, nvars);
+    if (initial) memcpy(state, initial, nvars);
+    else if (t0 == 0)
+        for (size_t i = 0; i < nvars; i++) {
+            size_t p = G.pos[i], w = p >> 5;
+            uint32_t r[4];
+            philox_seeded(seed, (uint32_t)(w >> 2), 0, 0, DOM_GEN_INIT, r);
+            state[i] = (uint8_t)((r[w & 3] >> (p & 31)) & 1u);
+        }
+    /* (t0 != 0 with initial == NULL: continue from the state already in `state`) */
+    uint8_t *next = malloc(nvars ? nvars : 1);
+    for (size_t k = 0; k < timesteps; k++) {
+        uint64_t t = t0 + k;
+        double beta = betas[k];
+        for (uint32_t c = 0; c < G.ncolours; c++) {
+            memcpy(next, state, nvars);
+            for (size_t i = 0; i < nvars; i++) {
+                if (G.colour[i] != c) continue;
+                double si = state[i] ? 1.0 : -1.0;
+                double field = 0.0;
+                for (size_t e = G.A.ptr[i]; e < G.A.ptr[i + 1]; e++)
+                    field += G.A.w[e] * (state[G.A.nbr[e]] ? 1.0 : -1.0);
+                double dE = 2.0 * si * ((biases ? biases[i] : 0.0) - field);
+                int accept = dE <= 0.0;
+                if (!accept) {
+                    uint32_t r[4];
+                    philox_seeded(seed, (uint32_t)(i >> 1), (uint32_t)t, ctr2(t, 0, 0),
+                                  DOM_GEN_SWEEP, r);
+                    uint64_t x = ((uint64_t)r[2 * (i & 1) + 1] << 32) | r[2 * (i & 1)];
+                    double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+                    accept = u < orc_det_exp(-beta * dE);
+                }
+                if (accept) next[i] = !state[i];
+            }
+            memcpy(state, next, nvars);
+        }
+        if (energies_per_step)
+            energies_per_step[k] = orc_energy(n_edges, ea, eb, ej, nvars, biases, state);
+    }
+    free(next);
+    if (energy_out) *energy_out = orc_energy(n_edges, ea, eb, ej, nvars, biases, state);
+    gen_free(&G);
+}
+
+/* ==========================================================================================
+ * Parallel-tempering swap decision, shaped after the countdown loop of
+ * tempering.rs:172-212 (quantum in the reference; the classical ladder is the build's own).
+ * Round `round`, parity = round & 1: pairs (i, i+1) for i = parity, parity+2, ...; rung i holds
+ * replica slot perm[i].  Swap iff u53 < exp((beta_i - beta_j)(E_i - E_j)) with
+ * u = Philox(key = seed, (i, round_lo, round_hi, DOM_PT_SWAP)) words 0,1.  Swaps exchange the
+ * betas (perm entries), never the configurations.  Returns the number of accepted swaps.
+ * ======================================================================================== */
+uint64_t orc_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
+                           const double *slot_energy, uint32_t *perm)
+{
+    uint64_t swaps = 0;
+    for (size_t i = round & 1; i + 1 < n_rungs; i += 2) {
+        double d = (betas[i] - betas[i + 1]) * (slot_energy[perm[i]] - slot_energy[perm[i + 1]]);
+        int accept = d >= 0.0;
+        if (!accept) {
+            uint32_t r[4];
+            philox_seeded(seed, (uint32_t)i, (uint32_t)round, (uint32_t)(round >> 32), DOM_PT_SWAP, r);
+            uint64_t x = ((uint64_t)r[1] << 32) | r[0];
+            double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+            accept = u < orc_det_exp(d);
+        }
+        if (accept) {
+            uint32_t tmp = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = tmp;
+            swaps++;
+        }
+    }
+    return swaps;
+}

@@ -1,0 +1,190 @@
+"""ctypes front-end of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see the header of ising_oracle.c).  PARITY UNPINNED against the reference's `qmc` crate; pinned
+by published RNG vectors, README.md:45-46 energies, exact enumeration and Kaufman's solution.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
+        L.orc_xoshiro_from_state.argtypes = [u64p, C.c_size_t, u64p]
+        L.orc_make_seeds.argtypes = [C.c_uint64, C.c_size_t, u64p]
+        L.orc_energy.restype = C.c_double
+        L.orc_energy.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u8p]
+        L.orc_ref_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p,
+                                  C.c_size_t, C.c_void_p, f64p, C.c_size_t, u8p, C.c_void_p,
+                                  C.c_void_p]
+        L.orc_threshold40.restype = C.c_uint64
+        L.orc_threshold40.argtypes = [C.c_double, C.c_double]
+        L.orc_lat_supported.argtypes = [C.c_int, C.c_int]
+        L.orc_lat_state_words.restype = C.c_size_t
+        L.orc_lat_state_words.argtypes = [C.c_int, C.c_int]
+        L.orc_lat_init.argtypes = [C.c_int, C.c_int, C.c_uint64, u32p]
+        L.orc_lat_pack.argtypes = [C.c_int, C.c_int, u8p, u32p]
+        L.orc_lat_unpack.argtypes = [C.c_int, C.c_int, u32p, u8p]
+        L.orc_lat_sweep.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                    u32p, C.c_uint64, C.c_uint64, C.c_double]
+        L.orc_lat_energy_mag.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                         C.c_void_p, u32p, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int64)]
+        L.orc_det_exp.restype = C.c_double
+        L.orc_det_exp.argtypes = [C.c_double]
+        L.orc_gen_colouring.restype = C.c_uint32
+        L.orc_gen_colouring.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]
+        L.orc_gen_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p,
+                                  C.c_uint64, C.c_void_p, C.c_uint64, f64p, C.c_size_t, u8p,
+                                  C.c_void_p, C.c_void_p]
+        L.orc_pt_swap_round.restype = C.c_uint64
+        L.orc_pt_swap_round.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, f64p, f64p, u32p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def split_edges(edges):
+    """[((a, b), j), ...] (the reference's edge-list form, lattice.rs:47) -> three arrays."""
+    ea = np.ascontiguousarray([e[0][0] for e in edges], dtype=np.uint64)
+    eb = np.ascontiguousarray([e[0][1] for e in edges], dtype=np.uint64)
+    ej = np.ascontiguousarray([e[1] for e in edges], dtype=np.float64)
+    return ea, eb, ej
+
+
+def philox(ctr, key):
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(np.asarray(ctr, dtype=np.uint32), np.asarray(key, dtype=np.uint32), out)
+    return out
+
+
+def make_seeds(seed_gen, n):
+    out = np.zeros(n, dtype=np.uint64)
+    lib().orc_make_seeds(C.c_uint64(seed_gen), n, out)
+    return out
+
+
+def xoshiro_from_state(s, n):
+    out = np.zeros(n, dtype=np.uint64)
+    lib().orc_xoshiro_from_state(np.asarray(s, dtype=np.uint64), n, out)
+    return out
+
+
+def energy(ea, eb, ej, nvars, state, biases=None):
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    st = np.ascontiguousarray(state, dtype=np.uint8)
+    return lib().orc_energy(len(ea), ea, eb, ej, nvars, _ptr(b), st)
+
+
+def ref_run(ea, eb, ej, nvars, seeds, betas, biases=None, initial=None, per_step=False):
+    """Reference-faithful engine (random-site sequential Metropolis), R = len(seeds) chains."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    R, T = len(seeds), len(betas)
+    states = np.zeros((R, nvars), dtype=np.uint8)
+    energies = np.zeros(R, dtype=np.float64)
+    eps = np.zeros((R, T), dtype=np.float64) if per_step else None
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    ini = None if initial is None else np.ascontiguousarray(initial, dtype=np.uint8)
+    lib().orc_ref_run(len(ea), ea, eb, ej, nvars, _ptr(b), seeds, R, _ptr(ini), betas, T, states,
+                      _ptr(energies), _ptr(eps))
+    return (energies, states, eps) if per_step else (energies, states)
+
+
+def threshold40(beta, dE):
+    return int(lib().orc_threshold40(beta, dE))
+
+
+def det_exp(x):
+    return lib().orc_det_exp(x)
+
+
+class Lat:
+    """Checkerboard spec engine (engine B) for one replica of a periodic W x H lattice."""
+
+    def __init__(self, W, H, jabs=1.0, jpos_uniform=0, jright=None, jdown=None):
+        assert lib().orc_lat_supported(W, H), (W, H)
+        self.W, self.H, self.jabs, self.jpos = W, H, float(jabs), int(jpos_uniform)
+        self.jright = None if jright is None else np.ascontiguousarray(jright, dtype=np.uint8)
+        self.jdown = None if jdown is None else np.ascontiguousarray(jdown, dtype=np.uint8)
+        self.words = lib().orc_lat_state_words(W, H)
+
+    def init(self, seed):
+        st = np.zeros(self.words, dtype=np.uint32)
+        lib().orc_lat_init(self.W, self.H, C.c_uint64(int(seed)), st)
+        return st
+
+    def pack(self, spins):
+        st = np.zeros(self.words, dtype=np.uint32)
+        lib().orc_lat_pack(self.W, self.H, np.ascontiguousarray(spins, dtype=np.uint8).ravel(), st)
+        return st
+
+    def unpack(self, st):
+        out = np.zeros(self.W * self.H, dtype=np.uint8)
+        lib().orc_lat_unpack(self.W, self.H, st, out)
+        return out
+
+    def sweep(self, st, seed, t, beta):
+        lib().orc_lat_sweep(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright),
+                            _ptr(self.jdown), st, C.c_uint64(int(seed)), C.c_uint64(int(t)),
+                            float(beta))
+
+    def energy_mag(self, st):
+        e, m = C.c_double(), C.c_int64()
+        lib().orc_lat_energy_mag(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright),
+                                 _ptr(self.jdown), st, C.byref(e), C.byref(m))
+        return e.value, m.value
+
+
+def gen_colouring(ea, eb, ej, nvars):
+    colours = np.zeros(nvars, dtype=np.uint32)
+    pos = np.zeros(nvars, dtype=np.uint64)
+    nc = lib().orc_gen_colouring(len(ea), ea, eb, ej, nvars, _ptr(colours), _ptr(pos))
+    return nc, colours, pos
+
+
+def gen_run(ea, eb, ej, nvars, seed, betas, biases=None, initial=None, t0=0, state=None,
+            per_step=False):
+    """General-path spec engine (engine C), one replica. Returns (energy, state[, per-step E])."""
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    T = len(betas)
+    st = np.zeros(nvars, dtype=np.uint8) if state is None else np.ascontiguousarray(state, dtype=np.uint8)
+    e = C.c_double()
+    eps = np.zeros(T, dtype=np.float64) if per_step else None
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    ini = None if initial is None else np.ascontiguousarray(initial, dtype=np.uint8)
+    lib().orc_gen_run(len(ea), ea, eb, ej, nvars, _ptr(b), C.c_uint64(int(seed)), _ptr(ini),
+                      C.c_uint64(int(t0)), betas, T, st, C.cast(C.byref(e), C.c_void_p), _ptr(eps))
+    return (e.value, st, eps) if per_step else (e.value, st)
+
+
+def pt_swap_round(seed, rnd, betas, slot_energy, perm):
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    slot_energy = np.ascontiguousarray(slot_energy, dtype=np.float64)
+    return int(lib().orc_pt_swap_round(C.c_uint64(int(seed)), C.c_uint64(int(rnd)), len(betas),
+                                       betas, slot_energy, perm))

@@ -1,0 +1,13 @@
+"""Drop-in module name of the reference (src/lib.rs:14-22): `import py_monte_carlo`.
+
+Classical classes only (Lattice, ClassicIsing); the quantum SSE classes of the reference
+(QmcIsing, QmcRunner, LatticeTempering) are out of scope of this build.  ClassicalTempering is the
+build's classical beta-ladder shaped after LatticeTempering (tempering.rs).
+"""
+from pyisingmontecarlo_amd import load_extension as _load
+
+_ext = _load()
+Lattice = _ext.Lattice
+ClassicIsing = _ext.ClassicIsing
+
+__all__ = ["Lattice", "ClassicIsing"]

@@ -1,0 +1,251 @@
+"""ctypes binding of include/isingmc.h (libisingmc.so).  No fallback of any kind: if the HIP library
+is missing or no device is usable, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libisingmc.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = range(5)
+KIND_GENERAL, KIND_LATTICE2D = 0, 1
+FLAG_FORCE_GENERAL = 1
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("device", C.c_int32), ("nvars", C.c_uint64), ("n_edges", C.c_uint64),
+                ("width", C.c_int32), ("height", C.c_int32), ("jabs", C.c_double), ("uniform_sign", C.c_int32),
+                ("n_colours", C.c_uint32), ("state_words", C.c_uint64)]
+
+
+_vp = C.c_void_p
+_PROTOTYPES = {
+    "isingmc_last_error": (C.c_char_p, []),
+    "isingmc_abi_version": (C.c_int, []),
+    "isingmc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "isingmc_host_make_seeds": (C.c_int, [C.c_int, C.c_uint64, C.c_size_t, _vp]),
+    "isingmc_host_expand_schedule": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]),
+    "isingmc_host_recognise_lattice2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_int),
+                                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                                   C.POINTER(C.c_int)]),
+    "isingmc_host_colour_graph": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint32)]),
+    "isingmc_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_uint, C.POINTER(_vp)]),
+    "isingmc_graph_info": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
+    "isingmc_graph_destroy": (None, [_vp]),
+    "isingmc_states_create": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.POINTER(_vp)]),
+    "isingmc_states_append": (C.c_int, [_vp, C.c_uint64, _vp]),
+    "isingmc_states_set_state": (C.c_int, [_vp, C.c_size_t, _vp]),
+    "isingmc_states_count": (C.c_size_t, [_vp]),
+    "isingmc_states_destroy": (None, [_vp]),
+    "isingmc_states_set_betas": (C.c_int, [_vp, _vp]),
+    "isingmc_do_time_steps": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "isingmc_do_time_steps_timed": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_float)]),
+    "isingmc_get_energies": (C.c_int, [_vp, _vp]),
+    "isingmc_get_magnetisations": (C.c_int, [_vp, _vp]),
+    "isingmc_get_states": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "isingmc_get_packed_states": (C.c_int, [_vp, _vp]),
+    "isingmc_states_timestep": (C.c_uint64, [_vp]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m pyisingmontecarlo_amd.build` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.isingmc_abi_version() != 1:
+            raise RuntimeError("libisingmc.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    msg = (lib().isingmc_last_error() or b"").decode()
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_ALLOC:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _arr(x, dtype):
+    return None if x is None else np.ascontiguousarray(x, dtype=dtype)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().isingmc_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def make_seeds(seed_gen, n):
+    out = np.zeros(n, dtype=np.uint64)
+    _check(lib().isingmc_host_make_seeds(int(seed_gen is not None), C.c_uint64(seed_gen or 0), n, _p(out)))
+    return out
+
+
+def expand_schedule(stops, timesteps, compat_constant_beta=False):
+    t = _arr([s[0] for s in stops], np.uint64)
+    b = _arr([s[1] for s in stops], np.float64)
+    out = np.zeros(timesteps, dtype=np.float64)
+    _check(lib().isingmc_host_expand_schedule(_p(t), _p(b), len(stops), timesteps, int(compat_constant_beta), _p(out)))
+    return out
+
+
+def recognise_lattice2d(ea, eb, ej, nvars):
+    ea, eb, ej = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64)
+    ok, w, h, u, jabs = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    _check(lib().isingmc_host_recognise_lattice2d(_p(ea), _p(eb), _p(ej), len(ea), nvars, C.byref(ok), C.byref(w),
+                                                  C.byref(h), C.byref(jabs), C.byref(u)))
+    return dict(is_lattice=bool(ok.value), width=w.value, height=h.value, jabs=jabs.value,
+                uniform_sign=bool(u.value))
+
+
+def colour_graph(ea, eb, nvars):
+    ea, eb = _arr(ea, np.uint64), _arr(eb, np.uint64)
+    colours = np.zeros(nvars, dtype=np.uint32)
+    nc = C.c_uint32()
+    _check(lib().isingmc_host_colour_graph(_p(ea), _p(eb), len(ea), nvars, _p(colours), C.byref(nc)))
+    return nc.value, colours
+
+
+class Graph:
+    """isingmc_graph: edges (+ biases) resident on one device."""
+
+    def __init__(self, ea, eb, ej, nvars=None, biases=None, device=0, force_general=False):
+        self._h = _vp()
+        ea, eb, ej = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64)
+        if nvars is None:
+            nvars = int(max(ea.max(), eb.max())) + 1 if len(ea) else 0
+        biases = _arr(biases, np.float64)
+        _check(lib().isingmc_graph_create(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(biases), device,
+                                          FLAG_FORCE_GENERAL if force_general else 0, C.byref(self._h)))
+        info = GraphInfo()
+        _check(lib().isingmc_graph_info(self._h, C.byref(info)))
+        self.info = info
+        self.nvars = int(info.nvars)
+        self.kind = int(info.kind)
+        self.state_words = int(info.state_words)
+
+    def close(self):
+        if self._h:
+            lib().isingmc_graph_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class States:
+    """isingmc_states: R replicas of the graph's spins on the device."""
+
+    def __init__(self, graph, seeds, initial_state=None):
+        self.graph = graph  # keeps the graph alive
+        self._h = _vp()
+        seeds = _arr(seeds, np.uint64)
+        ini = _arr(initial_state, np.uint8)
+        if ini is not None and ini.size != graph.nvars:
+            raise ValueError("Initial state must be of the same size as biases, or 0.")
+        _check(lib().isingmc_states_create(graph._h, len(seeds), _p(seeds), _p(ini), C.byref(self._h)))
+
+    @property
+    def count(self):
+        return int(lib().isingmc_states_count(self._h))
+
+    @property
+    def timestep(self):
+        return int(lib().isingmc_states_timestep(self._h))
+
+    def append(self, seed, initial_state=None):
+        ini = _arr(initial_state, np.uint8)
+        _check(lib().isingmc_states_append(self._h, C.c_uint64(int(seed)), _p(ini)))
+
+    def set_state(self, replica, state):
+        st = _arr(state, np.uint8)
+        if st.size != self.graph.nvars:
+            raise ValueError("Initial state must be of the same size as biases, or 0.")
+        _check(lib().isingmc_states_set_state(self._h, replica, _p(st)))
+
+    def set_betas(self, betas):
+        b = _arr(betas, np.float64)
+        if b is not None and b.size != self.count:
+            raise ValueError("one beta per replica expected")
+        _check(lib().isingmc_states_set_betas(self._h, _p(b)))
+
+    def do_time_steps(self, timesteps, beta=None, per_step_energies=False):
+        """beta: float (constant), sequence of length timesteps, or None when per-replica betas are set."""
+        R = self.count
+        if beta is None:
+            b, stride = None, 0
+        elif np.ndim(beta) == 0:
+            b, stride = np.array([beta], dtype=np.float64), 0
+        else:
+            b, stride = _arr(beta, np.float64), 1
+            if b.size != timesteps:
+                raise ValueError("need one beta per timestep")
+        out = np.zeros((R, timesteps), dtype=np.float64) if per_step_energies else None
+        _check(lib().isingmc_do_time_steps(self._h, timesteps, _p(b), stride, _p(out)))
+        return out
+
+    def do_time_steps_timed(self, timesteps, beta):
+        b = np.array([beta], dtype=np.float64) if np.ndim(beta) == 0 else _arr(beta, np.float64)
+        ms = C.c_float()
+        _check(lib().isingmc_do_time_steps_timed(self._h, timesteps, _p(b), 0 if b.size == 1 else 1, C.byref(ms)))
+        return ms.value
+
+    def energies(self):
+        out = np.zeros(self.count, dtype=np.float64)
+        _check(lib().isingmc_get_energies(self._h, _p(out)))
+        return out
+
+    def magnetisations(self):
+        out = np.zeros(self.count, dtype=np.int64)
+        _check(lib().isingmc_get_magnetisations(self._h, _p(out)))
+        return out
+
+    def states(self, out=None):
+        """bool[R, nvars]; `out` may be a C-contiguous (R, ..., nvars)-strided uint8/bool view base."""
+        R, N = self.count, self.graph.nvars
+        if out is None:
+            out = np.zeros((R, N), dtype=np.bool_)
+            stride = N
+        else:
+            stride = out.strides[0]
+        _check(lib().isingmc_get_states(self._h, out.ctypes.data_as(_vp), stride))
+        return out
+
+    def packed(self):
+        out = np.zeros((self.count, self.graph.state_words), dtype=np.uint32)
+        _check(lib().isingmc_get_packed_states(self._h, _p(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().isingmc_states_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,179 @@
+// General edge-list path: greedy-coloured independent sets, CSR gather, f64 local fields.
+// Replaces the serial do_time_step loop (lattice.rs:204-207) for any graph the lattice recogniser
+// rejects.  DESIGN.md S4; the CPU oracle (engine C) reproduces the configurations bit for bit, which
+// is why every f64 operation below is written out (explicit fma, -ffp-contract=off).
+//
+// Layout: sites are renumbered colour-major ("positions"), each colour class padded to a multiple
+// of 64 so that one wavefront covers 64 positions of ONE class = exactly two packed state words;
+// the flip mask of a wave is its __ballot, written by lane 0 -- no atomics.
+#pragma once
+#include "philox.hpp"
+
+namespace isingmc {
+
+constexpr uint32_t PAD_SITE = 0xFFFFFFFFu;
+
+struct GenGraphDev {
+    const uint32_t *rowptr;  // n_pos + 1
+    const uint32_t *nbr;     // neighbour POSITIONS
+    const void *w;           // couplings, float (when lossless) or double
+    const double *bias;      // per position, or nullptr (all zero)
+    const uint32_t *site;    // original site id per position, PAD_SITE on padding
+    uint32_t n_pos;          // multiple of 64
+    uint32_t n_words;        // n_pos / 32
+};
+
+// exp(x) for x = -beta dE, IEEE f64 ops + fma only (same bits as the oracle's orc_det_exp)
+__device__ __forceinline__ double det_exp(double x)
+{
+    if (x >= 0.0) return 1.0;
+    if (x < -40.0) return 0.0; // below 2^-53: can never beat a 53-bit uniform
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double kf = floor(fma(x, LOG2E, 0.5));
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long k = (long long)kf; // in [-58, 0]
+    return p * __longlong_as_double((1023ll + k) << 52);
+}
+
+template <typename WT>
+__device__ __forceinline__ double local_field(const GenGraphDev &G, const uint32_t *__restrict__ st,
+                                              uint32_t p)
+{
+    const WT *w = static_cast<const WT *>(G.w);
+    double field = 0.0;
+    for (uint32_t e = G.rowptr[p], end = G.rowptr[p + 1]; e < end; e++) {
+        const uint32_t q = G.nbr[e];
+        const double j = double(w[e]);
+        field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
+    }
+    return field;
+}
+
+// one colour class of one timestep, all replicas (blockIdx.y)
+template <typename WT>
+__global__ __launch_bounds__(256) void gen_sweep_kernel(
+    uint32_t *__restrict__ state, const GenGraphDev G, const uint32_t class_begin,
+    const uint32_t class_end, const uint64_t t, const uint2 *__restrict__ keys,
+    const double beta_uniform, const double *__restrict__ beta_replica)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t p = class_begin + blockIdx.x * 256 + threadIdx.x;
+    if (p >= class_end) return; // class sizes are multiples of 64: whole waves leave together
+    uint32_t *st = state + size_t(r) * G.n_words;
+    const uint32_t site = G.site[p];
+    bool flip = false;
+    if (site != PAD_SITE) {
+        const double beta = beta_replica ? beta_replica[r] : beta_uniform;
+        const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
+        const double field = local_field<WT>(G, st, p);
+        const double dE = 2.0 * si * ((G.bias ? G.bias[p] : 0.0) - field);
+        flip = dE <= 0.0;
+        if (!flip) {
+            const uint4 rnd =
+                philox4x32_10(make_uint4(site >> 1, uint32_t(t), ctr2(t, 0, 0), DOM_GEN_SWEEP), keys[r]);
+            const uint64_t x = (site & 1u) ? (uint64_t(rnd.w) << 32 | rnd.z) : (uint64_t(rnd.y) << 32 | rnd.x);
+            const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
+            flip = u < det_exp(-beta * dE);
+        }
+    }
+    const unsigned long long mask = __ballot(flip);
+    if ((threadIdx.x & 63) == 0 && mask) {
+        st[p >> 5] ^= uint32_t(mask);
+        st[(p >> 5) + 1] ^= uint32_t(mask >> 32);
+    }
+}
+
+// random start: packed word w = Philox(key, (w>>2, 0, 0, "GENI"))[w&3], padding bits cleared
+__global__ __launch_bounds__(256) void gen_init_kernel(uint32_t *__restrict__ state,
+                                                       const GenGraphDev G,
+                                                       const uint2 *__restrict__ keys,
+                                                       const uint32_t first_replica)
+{
+    const uint32_t r = first_replica + blockIdx.y;
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= G.n_words) return;
+    const uint4 rnd = philox4x32_10(make_uint4(w >> 2, 0, 0, DOM_GEN_INIT), keys[r]);
+    uint32_t v = (w & 3) == 0 ? rnd.x : (w & 3) == 1 ? rnd.y : (w & 3) == 2 ? rnd.z : rnd.w;
+    uint32_t valid = 0;
+    for (int b = 0; b < 32; b++) valid |= uint32_t(G.site[32 * w + b] != PAD_SITE) << b;
+    state[size_t(r) * G.n_words + w] = v & valid;
+}
+
+// per-block partial sums of E = sum_i s_i (field_i / 2 - h_i) and of M = sum_i s_i.
+// partial_e[r][block], partial_m[r][block]; a second pass adds them in a fixed order, so the result
+// is reproducible run to run (no floating-point atomics).
+template <typename WT>
+__global__ __launch_bounds__(256) void gen_measure_kernel(const uint32_t *__restrict__ state,
+                                                          const GenGraphDev G,
+                                                          double *__restrict__ partial_e,
+                                                          long long *__restrict__ partial_m)
+{
+    __shared__ double se[4];
+    __shared__ long long sm[4];
+    const uint32_t r = blockIdx.y;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t *st = state + size_t(r) * G.n_words;
+    double e = 0.0;
+    long long m = 0;
+    if (p < G.n_pos && G.site[p] != PAD_SITE) {
+        const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
+        const double field = local_field<WT>(G, st, p);
+        e = si * (0.5 * field - (G.bias ? G.bias[p] : 0.0));
+        m = (long long)si;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        e += __shfl_xor(e, off);
+        m += __shfl_xor(m, off);
+    }
+    if ((threadIdx.x & 63) == 0) { se[threadIdx.x >> 6] = e; sm[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial_e[size_t(r) * gridDim.x + blockIdx.x] = (se[0] + se[1]) + (se[2] + se[3]);
+        partial_m[size_t(r) * gridDim.x + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// fixed-order tree sum of one replica's partials: out_e[r], out_m[r]
+__global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restrict__ partial_e,
+                                                         const long long *__restrict__ partial_m,
+                                                         const uint32_t n_partials,
+                                                         double *__restrict__ out_e,
+                                                         long long *__restrict__ out_m)
+{
+    __shared__ double se[256];
+    __shared__ long long sm[256];
+    const uint32_t r = blockIdx.x;
+    double e = 0.0;
+    long long m = 0;
+    for (uint32_t i = threadIdx.x; i < n_partials; i += 256) {
+        e += partial_e[size_t(r) * n_partials + i];
+        m += partial_m[size_t(r) * n_partials + i];
+    }
+    se[threadIdx.x] = e;
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { se[threadIdx.x] += se[threadIdx.x + s]; sm[threadIdx.x] += sm[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_e[r] = se[0]; out_m[r] = sm[0]; }
+}
+
+} // namespace isingmc

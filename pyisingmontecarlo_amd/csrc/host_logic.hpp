@@ -1,0 +1,58 @@
+// Host-side logic of libisingmc.so that needs no device: seeds, schedules, lattice recogniser,
+// adjacency + greedy colouring.  See include/isingmc.h for the reference lines each part replaces.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace isingmc {
+
+// xoshiro256++ seeded by SplitMix64: rand 0.8 SmallRng::seed_from_u64 on 64-bit targets
+// (published algorithm; what lattice.rs:85-90 instantiates).
+struct SmallRng {
+    uint64_t s[4];
+    explicit SmallRng(uint64_t seed);
+    uint64_t next_u64();
+};
+
+std::vector<uint64_t> make_seeds(bool has_seed, uint64_t seed_gen, size_t n);
+
+// lattice.rs:320-334 + 358-365; returns "" or an error message
+std::string expand_schedule(const uint64_t *stop_t, const double *stop_beta, size_t n_stops,
+                            size_t timesteps, bool compat_constant_beta, double *betas_out);
+
+struct Lattice2D {
+    bool ok = false;
+    int W = 0, H = 0;
+    double jabs = 0.0;
+    bool uniform_sign = true;
+    bool jpos_uniform = false;          // sign when uniform: true = J > 0 (antiferromagnetic)
+    std::vector<uint8_t> jright, jdown; // per site: 1 if that bond has J > 0 (empty when uniform)
+};
+
+Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const double *ej,
+                              size_t n_edges, size_t nvars);
+
+// adjacency in edge-list order (self-loops dropped, their J summed into self_energy)
+struct Adjacency {
+    std::vector<uint64_t> ptr; // nvars + 1
+    std::vector<uint32_t> nbr;
+    std::vector<double> w;
+    double self_energy = 0.0;
+};
+
+Adjacency build_adjacency(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges,
+                          size_t nvars);
+
+struct Colouring {
+    std::vector<uint32_t> colour;     // per site
+    uint32_t n_colours = 0;
+    std::vector<uint64_t> class_base; // n_colours + 1, packed positions, classes padded to 64
+    std::vector<uint64_t> pos;        // site -> packed position
+    uint64_t n_pos = 0;
+};
+
+Colouring greedy_colouring(const Adjacency &A, size_t nvars);
+
+} // namespace isingmc

@@ -1,0 +1,833 @@
+// libisingmc.so: the C ABI of include/isingmc.h over the HIP kernels (gfx950 only).
+// Host orchestration only -- every Monte-Carlo operation runs in the kernels of
+// lattice_kernels.hpp / general_kernels.hpp.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/isingmc.h"
+#include "general_kernels.hpp"
+#include "host_logic.hpp"
+#include "lattice_kernels.hpp"
+
+using namespace isingmc;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t err__ = (expr);                                                                 \
+        if (err__ != hipSuccess)                                                                   \
+            return fail(err__ == hipErrorOutOfMemory ? ISINGMC_ERR_ALLOC : ISINGMC_ERR_HIP,        \
+                        std::string(#expr) + ": " + hipGetErrorString(err__));                     \
+    } while (0)
+
+#define TRY(expr)                                                                                  \
+    do {                                                                                           \
+        int rc__ = (expr);                                                                         \
+        if (rc__ != ISINGMC_OK) return rc__;                                                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct isingmc_graph {
+    int device = 0;
+    int kind = ISINGMC_KIND_GENERAL;
+    uint64_t nvars = 0, n_edges = 0;
+    uint64_t state_words = 0;
+    bool has_bias = false;
+    // lattice path
+    LatGeom geom{};
+    bool vec = false;
+    double jabs = 0.0;
+    bool uniform_sign = true;
+    uint32_t jneg_uniform = 0;
+    uint32_t *d_jneg = nullptr; // [2 colours][4 directions][wpp]
+    // general path
+    GenGraphDev gdev{};
+    bool w_is_float = false;
+    std::vector<uint64_t> class_base;
+    std::vector<uint64_t> pos; // site -> packed position
+    double self_energy = 0.0;
+    uint32_t n_colours = 2;
+    std::vector<void *> dev_allocs;
+
+    ~isingmc_graph()
+    {
+        (void)hipSetDevice(device);
+        for (void *p : dev_allocs) (void)hipFree(p);
+    }
+};
+
+struct isingmc_states {
+    isingmc_graph *g = nullptr;
+    size_t R = 0, cap = 0;
+    uint32_t *d_state = nullptr;
+    uint2 *d_keys = nullptr;
+    uint64_t t = 0; // absolute timestep = Philox counter
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool has_betas = false;
+    std::vector<double> betas;
+    LatThr *d_thr = nullptr;
+    double *d_beta = nullptr;
+    // measurement scratch
+    unsigned long long *d_meas = nullptr; // lattice: [R][2]
+    double *d_pe = nullptr, *d_oe = nullptr;
+    long long *d_pm = nullptr, *d_om = nullptr;
+    uint32_t n_partials = 0;
+
+    ~isingmc_states()
+    {
+        if (!g) return;
+        (void)hipSetDevice(g->device);
+        for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
+                        (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
+            if (p) (void)hipFree(p);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+template <typename T>
+static int dev_alloc(T **out, size_t count)
+{
+    *out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T)));
+    return ISINGMC_OK;
+}
+
+template <typename T>
+static int graph_upload(isingmc_graph *g, const T **dst, const std::vector<T> &src)
+{
+    T *d = nullptr;
+    TRY(dev_alloc(&d, src.size()));
+    g->dev_allocs.push_back(d);
+    if (!src.empty()) HIP_TRY(hipMemcpy(d, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = d;
+    return ISINGMC_OK;
+}
+
+static int use_device(int device)
+{
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0)
+        return fail(ISINGMC_ERR_NO_DEVICE,
+                    std::string("no HIP device available (libisingmc has no CPU fallback): ") +
+                        hipGetErrorString(err));
+    if (device < 0 || device >= count)
+        return fail(ISINGMC_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range (" +
+                                               std::to_string(count) + " devices)");
+    HIP_TRY(hipSetDevice(device));
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small host helpers
+// ------------------------------------------------------------------------------------------------
+static uint64_t threshold40(double beta, double dE)
+{
+    const uint64_t ONE = uint64_t(1) << 40;
+    if (dE <= 0.0) return ONE;
+    const double p = std::exp(-beta * dE);
+    if (!(p < 1.0)) return ONE;
+    return uint64_t(std::floor(p * 1099511627776.0));
+}
+
+static LatThr lattice_thresholds(double beta, double jabs)
+{
+    return LatThr{threshold40(beta, 4.0 * jabs), threshold40(beta, 8.0 * jabs)};
+}
+
+template <typename F>
+static void parallel_for(size_t n, F &&body)
+{
+    const size_t nthreads = std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+    if (nthreads <= 1) {
+        for (size_t i = 0; i < n; i++) body(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (size_t tid = 0; tid < nthreads; tid++)
+        pool.emplace_back([&, tid] {
+            for (size_t i = tid; i < n; i += nthreads) body(i);
+        });
+    for (auto &th : pool) th.join();
+}
+
+// bytes (site order) -> packed words of one replica
+static void pack_state(const isingmc_graph *g, const uint8_t *spins, uint32_t *words)
+{
+    std::fill(words, words + g->state_words, 0u);
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        const LatGeom &L = g->geom;
+        for (uint32_t y = 0; y < L.H; y++)
+            for (uint32_t x = 0; x < L.W; x++)
+                if (spins[size_t(y) * L.W + x]) {
+                    const uint32_t c = (x + y) & 1, i = x >> 1;
+                    words[size_t(c) * L.wpp + size_t(y) * L.wpr + (i >> 5)] |= 1u << (i & 31);
+                }
+    } else {
+        for (uint64_t i = 0; i < g->nvars; i++)
+            if (spins[i]) words[g->pos[i] >> 5] |= 1u << (g->pos[i] & 31);
+    }
+}
+
+// packed words of one replica -> bytes (site order)
+static void unpack_state(const isingmc_graph *g, const uint32_t *words, uint8_t *spins)
+{
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        const LatGeom &L = g->geom;
+        for (uint32_t y = 0; y < L.H; y++) {
+            const uint32_t *row0 = words + size_t(y) * L.wpr, *row1 = row0 + L.wpp;
+            uint8_t *out = spins + size_t(y) * L.W;
+            const uint32_t o0 = y & 1; // x offset of colour 0 in this row
+            for (uint32_t xw = 0; xw < L.wpr; xw++) {
+                const uint32_t w0 = row0[xw], w1 = row1[xw];
+                uint8_t *o = out + 64 * xw;
+                for (uint32_t b = 0; b < 32; b++) {
+                    o[2 * b + o0] = (w0 >> b) & 1u;
+                    o[2 * b + 1 - o0] = (w1 >> b) & 1u;
+                }
+            }
+        }
+    } else {
+        for (uint64_t i = 0; i < g->nvars; i++) spins[i] = (words[g->pos[i] >> 5] >> (g->pos[i] & 31)) & 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: misc + host-only helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *isingmc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int isingmc_abi_version(void) { return ISINGMC_ABI_VERSION; }
+
+extern "C" int isingmc_device_count(int *count)
+{
+    if (!count) return fail(ISINGMC_ERR_INVALID, "count is NULL");
+    *count = 0;
+    hipError_t err = hipGetDeviceCount(count);
+    if (err != hipSuccess) {
+        *count = 0;
+        return fail(ISINGMC_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(err));
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_make_seeds(int has_seed, uint64_t seed_gen, size_t n, uint64_t *seeds_out)
+{
+    if (n && !seeds_out) return fail(ISINGMC_ERR_INVALID, "seeds_out is NULL");
+    const auto seeds = make_seeds(has_seed != 0, seed_gen, n);
+    std::copy(seeds.begin(), seeds.end(), seeds_out);
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_expand_schedule(const uint64_t *stop_t, const double *stop_beta, size_t n_stops,
+                                            size_t timesteps, int compat_constant_beta, double *betas_out)
+{
+    if ((n_stops && (!stop_t || !stop_beta)) || (timesteps && !betas_out))
+        return fail(ISINGMC_ERR_INVALID, "NULL schedule argument");
+    const std::string msg = expand_schedule(stop_t, stop_beta, n_stops, timesteps, compat_constant_beta != 0, betas_out);
+    return msg.empty() ? ISINGMC_OK : fail(ISINGMC_ERR_INVALID, msg);
+}
+
+static int check_edges(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars)
+{
+    if (n_edges == 0) return fail(ISINGMC_ERR_INVALID, "Must supply some edges for graph"); // lattice.rs:70-72
+    if (!ea || !eb || !ej) return fail(ISINGMC_ERR_INVALID, "NULL edge array");
+    if (nvars == 0 || nvars > 0xFFFFFFF0ull) return fail(ISINGMC_ERR_INVALID, "nvars out of range (1 .. 2^32-16)");
+    for (size_t k = 0; k < n_edges; k++) {
+        if (ea[k] >= nvars || eb[k] >= nvars)
+            return fail(ISINGMC_ERR_INVALID, "Index out of bounds: edge " + std::to_string(k) + " touches variable " +
+                                                 std::to_string(std::max(ea[k], eb[k])) + " out of " + std::to_string(nvars));
+        if (!std::isfinite(ej[k])) return fail(ISINGMC_ERR_INVALID, "edge couplings must be finite");
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const double *ej,
+                                                size_t n_edges, size_t nvars, int *is_lattice, int *width,
+                                                int *height, double *jabs, int *uniform_sign)
+{
+    if (!is_lattice) return fail(ISINGMC_ERR_INVALID, "is_lattice is NULL");
+    TRY(check_edges(ea, eb, ej, n_edges, nvars));
+    const Lattice2D L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
+    *is_lattice = L.ok;
+    if (width) *width = L.W;
+    if (height) *height = L.H;
+    if (jabs) *jabs = L.jabs;
+    if (uniform_sign) *uniform_sign = L.uniform_sign;
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_colour_graph(const uint64_t *ea, const uint64_t *eb, size_t n_edges, size_t nvars,
+                                         uint32_t *colours_out, uint32_t *n_colours_out)
+{
+    std::vector<double> ones(n_edges, 1.0);
+    TRY(check_edges(ea, eb, ones.data(), n_edges, nvars));
+    const Adjacency A = build_adjacency(ea, eb, ones.data(), n_edges, nvars);
+    const Colouring C = greedy_colouring(A, nvars);
+    if (colours_out) std::copy(C.colour.begin(), C.colour.end(), colours_out);
+    if (n_colours_out) *n_colours_out = C.n_colours;
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph
+// ------------------------------------------------------------------------------------------------
+static bool lattice_fast_path_ok(const Lattice2D &L)
+{
+    if (!L.ok || L.W % 64 != 0) return false;
+    const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
+    return wpp % 4 == 0 && wpp < (uint64_t(1) << 31);
+}
+
+static int build_lattice(isingmc_graph *g, const Lattice2D &L)
+{
+    g->kind = ISINGMC_KIND_LATTICE2D;
+    LatGeom &G = g->geom;
+    G.W = L.W;
+    G.H = L.H;
+    G.wpr = L.W / 64;
+    G.wpp = G.H * G.wpr;
+    G.nquads = G.wpp / 4;
+    g->vec = G.wpr % 4 == 0;
+    g->jabs = L.jabs;
+    g->uniform_sign = L.uniform_sign;
+    g->jneg_uniform = L.jpos_uniform ? 0u : 0xFFFFFFFFu;
+    g->state_words = 2 * uint64_t(G.wpp);
+    g->n_colours = 2;
+    if (!L.uniform_sign) { // per-bond sign planes in each colour's compact layout
+        std::vector<uint32_t> jneg(size_t(8) * G.wpp, 0u);
+        const uint32_t W = G.W, H = G.H;
+        for (uint32_t c = 0; c < 2; c++)
+            for (uint32_t y = 0; y < H; y++) {
+                const uint32_t yu = (y + H - 1) % H, o = (y + c) & 1;
+                for (uint32_t i = 0; i < W / 2; i++) {
+                    const uint32_t x = 2 * i + o, xl = (x + W - 1) % W;
+                    const bool up = L.jdown[size_t(yu) * W + x], dn = L.jdown[size_t(y) * W + x];
+                    const bool left = L.jright[size_t(y) * W + xl], right = L.jright[size_t(y) * W + x];
+                    const bool ce = o ? left : right, si = o ? right : left;
+                    const size_t w = size_t(y) * G.wpr + (i >> 5);
+                    const uint32_t bit = 1u << (i & 31);
+                    uint32_t *base = jneg.data() + size_t(c) * 4 * G.wpp;
+                    if (!up) base[w] |= bit;
+                    if (!dn) base[G.wpp + w] |= bit;
+                    if (!ce) base[2 * size_t(G.wpp) + w] |= bit;
+                    if (!si) base[3 * size_t(G.wpp) + w] |= bit;
+                }
+            }
+        const uint32_t *d = nullptr;
+        TRY(graph_upload(g, &d, jneg));
+        g->d_jneg = const_cast<uint32_t *>(d);
+    }
+    return ISINGMC_OK;
+}
+
+static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                         size_t n_edges, size_t nvars, const double *biases)
+{
+    g->kind = ISINGMC_KIND_GENERAL;
+    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
+    if (A.nbr.size() >= 0xFFFFFFFFull) return fail(ISINGMC_ERR_INVALID, "too many edges for the general path (2^32 directed)");
+    const Colouring C = greedy_colouring(A, nvars);
+    if (C.n_pos >= 0xFFFFFFC0ull) return fail(ISINGMC_ERR_INVALID, "too many sites for the general path");
+    g->self_energy = A.self_energy;
+    g->n_colours = C.n_colours;
+    g->class_base = C.class_base;
+    g->pos = C.pos;
+    g->state_words = C.n_pos / 32;
+
+    const uint32_t n_pos = uint32_t(C.n_pos);
+    std::vector<uint32_t> site(n_pos, PAD_SITE), rowptr(size_t(n_pos) + 1, 0);
+    for (size_t i = 0; i < nvars; i++) site[C.pos[i]] = uint32_t(i);
+    for (uint32_t p = 0; p < n_pos; p++)
+        rowptr[p + 1] = rowptr[p] + (site[p] == PAD_SITE ? 0u : uint32_t(A.ptr[site[p] + 1] - A.ptr[site[p]]));
+    std::vector<uint32_t> nbr(A.nbr.size());
+    std::vector<double> w(A.w.size());
+    bool lossless = true;
+    for (uint32_t p = 0; p < n_pos; p++) {
+        if (site[p] == PAD_SITE) continue;
+        uint32_t o = rowptr[p];
+        for (uint64_t e = A.ptr[site[p]]; e < A.ptr[site[p] + 1]; e++, o++) {
+            nbr[o] = uint32_t(C.pos[A.nbr[e]]);
+            w[o] = A.w[e];
+            lossless &= double(float(A.w[e])) == A.w[e];
+        }
+    }
+    GenGraphDev &D = g->gdev;
+    D.n_pos = n_pos;
+    D.n_words = n_pos / 32;
+    TRY(graph_upload(g, &D.rowptr, rowptr));
+    TRY(graph_upload(g, &D.nbr, nbr));
+    TRY(graph_upload(g, &D.site, site));
+    g->w_is_float = lossless;
+    if (lossless) { // stream 4-byte couplings when that loses nothing (e.g. J = +-1)
+        std::vector<float> wf(w.begin(), w.end());
+        const float *d = nullptr;
+        TRY(graph_upload(g, &d, wf));
+        D.w = d;
+    } else {
+        const double *d = nullptr;
+        TRY(graph_upload(g, &d, w));
+        D.w = d;
+    }
+    D.bias = nullptr;
+    if (g->has_bias) {
+        std::vector<double> bias(n_pos, 0.0);
+        for (size_t i = 0; i < nvars; i++) bias[C.pos[i]] = biases[i];
+        TRY(graph_upload(g, &D.bias, bias));
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_graph_create(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges,
+                                    size_t nvars, const double *biases, int device, unsigned flags,
+                                    isingmc_graph **graph_out)
+{
+    if (!graph_out) return fail(ISINGMC_ERR_INVALID, "graph_out is NULL");
+    *graph_out = nullptr;
+    TRY(check_edges(ea, eb, ej, n_edges, nvars));
+    bool has_bias = false;
+    if (biases)
+        for (size_t i = 0; i < nvars; i++) {
+            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
+            has_bias |= biases[i] != 0.0;
+        }
+    TRY(use_device(device));
+    auto g = std::make_unique<isingmc_graph>();
+    g->device = device;
+    g->nvars = nvars;
+    g->n_edges = n_edges;
+    g->has_bias = has_bias;
+    Lattice2D L;
+    if (!(flags & ISINGMC_FLAG_FORCE_GENERAL) && !has_bias) L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
+    if (lattice_fast_path_ok(L)) TRY(build_lattice(g.get(), L));
+    else TRY(build_general(g.get(), ea, eb, ej, n_edges, nvars, biases));
+    *graph_out = g.release();
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *info)
+{
+    if (!g || !info) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    std::memset(info, 0, sizeof *info);
+    info->kind = g->kind;
+    info->device = g->device;
+    info->nvars = g->nvars;
+    info->n_edges = g->n_edges;
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        info->width = int32_t(g->geom.W);
+        info->height = int32_t(g->geom.H);
+        info->jabs = g->jabs;
+        info->uniform_sign = g->uniform_sign;
+    }
+    info->n_colours = g->n_colours;
+    info->state_words = g->state_words;
+    return ISINGMC_OK;
+}
+
+extern "C" void isingmc_graph_destroy(isingmc_graph *g) { delete g; }
+
+// ------------------------------------------------------------------------------------------------
+// states
+// ------------------------------------------------------------------------------------------------
+static dim3 lat_grid(const isingmc_graph *g, uint32_t quads, size_t replicas)
+{
+    (void)g;
+    return dim3((quads + 255) / 256, unsigned(replicas), 1);
+}
+
+constexpr size_t MAX_GRID_Y = 32768;
+
+// random start for replicas [first, first+count)
+static int init_random(isingmc_states *s, size_t first, size_t count)
+{
+    const isingmc_graph *g = s->g;
+    for (size_t r0 = first; r0 < first + count; r0 += MAX_GRID_Y) {
+        const size_t n = std::min(MAX_GRID_Y, first + count - r0);
+        if (g->kind == ISINGMC_KIND_LATTICE2D)
+            hipLaunchKernelGGL(lat_init_kernel, lat_grid(g, 2 * g->geom.nquads, n), dim3(256), 0, s->stream,
+                               s->d_state, g->geom, s->d_keys, uint32_t(r0));
+        else
+            hipLaunchKernelGGL(gen_init_kernel, dim3((g->gdev.n_words + 255) / 256, unsigned(n)), dim3(256), 0,
+                               s->stream, s->d_state, g->gdev, s->d_keys, uint32_t(r0));
+        HIP_TRY(hipGetLastError());
+    }
+    return ISINGMC_OK;
+}
+
+static int upload_state(isingmc_states *s, size_t first, size_t count, const uint8_t *spins)
+{
+    std::vector<uint32_t> words(s->g->state_words);
+    pack_state(s->g, spins, words.data());
+    for (size_t r = first; r < first + count; r++)
+        HIP_TRY(hipMemcpyAsync(s->d_state + r * s->g->state_words, words.data(), words.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ISINGMC_OK;
+}
+
+static int reserve(isingmc_states *s, size_t cap)
+{
+    if (cap <= s->cap) return ISINGMC_OK;
+    const isingmc_graph *g = s->g;
+    uint32_t *d_state = nullptr;
+    uint2 *d_keys = nullptr;
+    TRY(dev_alloc(&d_state, cap * g->state_words));
+    TRY(dev_alloc(&d_keys, cap));
+    if (s->R) {
+        HIP_TRY(hipMemcpy(d_state, s->d_state, s->R * g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->R * sizeof(uint2), hipMemcpyDeviceToDevice));
+    }
+    for (void *p : {(void *)s->d_state, (void *)s->d_keys, (void *)s->d_thr, (void *)s->d_beta, (void *)s->d_meas,
+                    (void *)s->d_pe, (void *)s->d_oe, (void *)s->d_pm, (void *)s->d_om})
+        if (p) HIP_TRY(hipFree(p));
+    s->d_state = d_state;
+    s->d_keys = d_keys;
+    s->d_thr = nullptr; s->d_beta = nullptr; s->d_meas = nullptr;
+    s->d_pe = nullptr; s->d_oe = nullptr; s->d_pm = nullptr; s->d_om = nullptr;
+    TRY(dev_alloc(&s->d_thr, cap));
+    TRY(dev_alloc(&s->d_beta, cap));
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        TRY(dev_alloc(&s->d_meas, 2 * cap));
+    } else {
+        s->n_partials = (g->gdev.n_pos + 255) / 256;
+        TRY(dev_alloc(&s->d_pe, cap * s->n_partials));
+        TRY(dev_alloc(&s->d_pm, cap * s->n_partials));
+        TRY(dev_alloc(&s->d_oe, cap));
+        TRY(dev_alloc(&s->d_om, cap));
+    }
+    s->cap = cap;
+    return ISINGMC_OK;
+}
+
+static int add_replicas(isingmc_states *s, size_t count, const uint64_t *seeds, const uint8_t *initial_state)
+{
+    const size_t first = s->R;
+    if (first + count > s->cap) TRY(reserve(s, std::max(first + count, s->cap + s->cap / 2)));
+    std::vector<uint2> keys(count);
+    for (size_t i = 0; i < count; i++) keys[i] = make_uint2(uint32_t(seeds[i]), uint32_t(seeds[i] >> 32));
+    if (count) HIP_TRY(hipMemcpy(s->d_keys + first, keys.data(), count * sizeof(uint2), hipMemcpyHostToDevice));
+    s->R = first + count;
+    if (initial_state) TRY(upload_state(s, first, count, initial_state));
+    else {
+        TRY(init_random(s, first, count));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const uint64_t *seeds,
+                                     const uint8_t *initial_state, isingmc_states **states_out)
+{
+    if (!g || !states_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    *states_out = nullptr;
+    if (n_replicas && !seeds) return fail(ISINGMC_ERR_INVALID, "seeds is NULL");
+    TRY(use_device(g->device));
+    auto s = std::make_unique<isingmc_states>();
+    s->g = g;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    TRY(reserve(s.get(), std::max<size_t>(n_replicas, 1)));
+    TRY(add_replicas(s.get(), n_replicas, seeds, initial_state));
+    *states_out = s.release();
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_states_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (s->has_betas) return fail(ISINGMC_ERR_INVALID, "clear the per-replica betas before appending replicas");
+    TRY(use_device(s->g->device));
+    return add_replicas(s, 1, &seed, initial_state);
+}
+
+extern "C" int isingmc_states_set_state(isingmc_states *s, size_t replica, const uint8_t *state)
+{
+    if (!s || !state) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (replica >= s->R) return fail(ISINGMC_ERR_INVALID, "replica index out of range");
+    TRY(use_device(s->g->device));
+    return upload_state(s, replica, 1, state);
+}
+
+extern "C" size_t isingmc_states_count(const isingmc_states *s) { return s ? s->R : 0; }
+
+extern "C" uint64_t isingmc_states_timestep(const isingmc_states *s) { return s ? s->t : 0; }
+
+extern "C" void isingmc_states_destroy(isingmc_states *s) { delete s; }
+
+extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_per_replica)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (!beta_per_replica) {
+        s->has_betas = false;
+        s->betas.clear();
+        return ISINGMC_OK;
+    }
+    for (size_t r = 0; r < s->R; r++)
+        if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
+    TRY(use_device(s->g->device));
+    s->betas.assign(beta_per_replica, beta_per_replica + s->R);
+    if (s->g->kind == ISINGMC_KIND_LATTICE2D) {
+        std::vector<LatThr> thr(s->R);
+        for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds(s->betas[r], s->g->jabs);
+        if (s->R) HIP_TRY(hipMemcpyAsync(s->d_thr, thr.data(), s->R * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
+    } else if (s->R) {
+        HIP_TRY(hipMemcpyAsync(s->d_beta, s->betas.data(), s->R * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->has_betas = true;
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweeps
+// ------------------------------------------------------------------------------------------------
+template <bool VEC, bool PMJ>
+static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &thr)
+{
+    const isingmc_graph *g = s->g;
+    for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
+        const size_t n = std::min(MAX_GRID_Y, s->R - r0);
+        hipLaunchKernelGGL((lat_sweep_kernel<VEC, PMJ>), lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
+                           s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                           s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
+    }
+}
+
+template <bool VEC, bool PMJ>
+static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_t out_stride)
+{
+    const isingmc_graph *g = s->g;
+    for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
+        const size_t n = std::min(MAX_GRID_Y, s->R - r0);
+        hipLaunchKernelGGL((lat_measure_kernel<VEC, PMJ>), lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
+                           s->d_state + r0 * g->state_words, g->geom, g->d_jneg, g->jneg_uniform,
+                           out + r0 * out_stride, out_stride);
+    }
+}
+
+#define LAT_DISPATCH(fn, ...)                                                                       \
+    do {                                                                                            \
+        const bool pmj__ = !s->g->uniform_sign;                                                     \
+        if (s->g->vec) { if (pmj__) fn<true, true>(__VA_ARGS__); else fn<true, false>(__VA_ARGS__); } \
+        else { if (pmj__) fn<false, true>(__VA_ARGS__); else fn<false, false>(__VA_ARGS__); }       \
+    } while (0)
+
+static void launch_gen_timestep(isingmc_states *s, double beta)
+{
+    const isingmc_graph *g = s->g;
+    for (uint32_t c = 0; c < g->n_colours; c++) {
+        const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
+        if (e == b) continue;
+        for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
+            const size_t n = std::min(MAX_GRID_Y, s->R - r0);
+            const dim3 grid((e - b + 255) / 256, unsigned(n));
+            const double *br = s->has_betas ? s->d_beta + r0 : nullptr;
+            if (g->w_is_float)
+                hipLaunchKernelGGL(gen_sweep_kernel<float>, grid, dim3(256), 0, s->stream,
+                                   s->d_state + r0 * g->state_words, g->gdev, b, e, s->t, s->d_keys + r0, beta, br);
+            else
+                hipLaunchKernelGGL(gen_sweep_kernel<double>, grid, dim3(256), 0, s->stream,
+                                   s->d_state + r0 * g->state_words, g->gdev, b, e, s->t, s->d_keys + r0, beta, br);
+        }
+    }
+}
+
+// energies / magnetisations of the current configurations into host arrays (either may be NULL)
+static int measure(isingmc_states *s, double *energies, int64_t *mags)
+{
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    if (R == 0) return ISINGMC_OK;
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
+        HIP_TRY(hipGetLastError());
+        std::vector<unsigned long long> h(2 * R);
+        HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const int64_t nbonds = 2 * int64_t(g->nvars);
+        for (size_t r = 0; r < R; r++) {
+            if (energies) energies[r] = g->jabs * double(nbonds - 2 * int64_t(h[2 * r]));
+            if (mags) mags[r] = 2 * int64_t(h[2 * r + 1]) - int64_t(g->nvars);
+        }
+    } else {
+        for (size_t r0 = 0; r0 < R; r0 += MAX_GRID_Y) {
+            const size_t n = std::min(MAX_GRID_Y, R - r0);
+            const dim3 grid(s->n_partials, unsigned(n));
+            if (g->w_is_float)
+                hipLaunchKernelGGL(gen_measure_kernel<float>, grid, dim3(256), 0, s->stream,
+                                   s->d_state + r0 * g->state_words, g->gdev, s->d_pe + r0 * s->n_partials,
+                                   s->d_pm + r0 * s->n_partials);
+            else
+                hipLaunchKernelGGL(gen_measure_kernel<double>, grid, dim3(256), 0, s->stream,
+                                   s->d_state + r0 * g->state_words, g->gdev, s->d_pe + r0 * s->n_partials,
+                                   s->d_pm + r0 * s->n_partials);
+        }
+        hipLaunchKernelGGL(gen_reduce_kernel, dim3(unsigned(R)), dim3(256), 0, s->stream, s->d_pe, s->d_pm,
+                           s->n_partials, s->d_oe, s->d_om);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> he(R);
+        std::vector<long long> hm(R);
+        HIP_TRY(hipMemcpyAsync(he.data(), s->d_oe, R * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(hm.data(), s->d_om, R * sizeof(long long), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        for (size_t r = 0; r < R; r++) {
+            if (energies) energies[r] = he[r] + g->self_energy;
+            if (mags) mags[r] = hm[r];
+        }
+    }
+    return ISINGMC_OK;
+}
+
+static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
+                     double *energies_per_step, float *device_ms)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (timesteps && !betas && !s->has_betas) return fail(ISINGMC_ERR_INVALID, "betas is NULL");
+    if (!s->has_betas)
+        for (size_t k = 0; k < timesteps; k++)
+            if (!std::isfinite(betas[k * beta_stride])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
+    if (device_ms) *device_ms = 0.f;
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    if (R == 0 || timesteps == 0) return ISINGMC_OK;
+    const bool lattice = g->kind == ISINGMC_KIND_LATTICE2D;
+
+    // per-step energies on the lattice path: integer counters per (step, replica), converted at the
+    // end of each chunk; on the general path one measure() per step.
+    const size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
+    unsigned long long *d_steps = nullptr;
+    std::vector<unsigned long long> h_steps;
+    if (energies_per_step && lattice) {
+        TRY(dev_alloc(&d_steps, chunk * R * 2));
+        h_steps.resize(chunk * R * 2);
+    }
+    int rc = ISINGMC_OK;
+    if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
+        const size_t nk = std::min(chunk, timesteps - k0);
+        if (d_steps) HIP_TRY(hipMemsetAsync(d_steps, 0, nk * R * 2 * sizeof(unsigned long long), s->stream));
+        for (size_t k = k0; k < k0 + nk; k++) {
+            const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
+            if (lattice) {
+                const LatThr thr = lattice_thresholds(beta, g->jabs);
+                LAT_DISPATCH(launch_lat_sweep, s, 0u, thr);
+                LAT_DISPATCH(launch_lat_sweep, s, 1u, thr);
+                if (d_steps) LAT_DISPATCH(launch_lat_measure, s, d_steps + (k - k0) * R * 2, size_t(2));
+            } else {
+                launch_gen_timestep(s, beta);
+            }
+            s->t++;
+            if (energies_per_step && !lattice) {
+                std::vector<double> e(R);
+                rc = measure(s, e.data(), nullptr);
+                if (rc != ISINGMC_OK) break;
+                for (size_t r = 0; r < R; r++) energies_per_step[r * timesteps + k] = e[r];
+            }
+        }
+        if (d_steps && rc == ISINGMC_OK) {
+            hipError_t err = hipMemcpyAsync(h_steps.data(), d_steps, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+            if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+            const int64_t nbonds = 2 * int64_t(g->nvars);
+            for (size_t k = 0; k < nk; k++)
+                for (size_t r = 0; r < R; r++)
+                    energies_per_step[r * timesteps + k0 + k] = g->jabs * double(nbonds - 2 * int64_t(h_steps[(k * R + r) * 2]));
+        }
+    }
+    if (device_ms && rc == ISINGMC_OK) {
+        hipError_t err = hipEventRecord(s->ev1, s->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(s->ev1);
+        if (err == hipSuccess) err = hipEventElapsedTime(device_ms, s->ev0, s->ev1);
+        if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+    }
+    if (d_steps) (void)hipFree(d_steps);
+    if (rc != ISINGMC_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_do_time_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
+                                     double *energies_per_step)
+{
+    return run_steps(s, timesteps, betas, beta_stride, energies_per_step, nullptr);
+}
+
+extern "C" int isingmc_do_time_steps_timed(isingmc_states *s, size_t timesteps, const double *betas,
+                                           size_t beta_stride, float *device_ms_out)
+{
+    if (!device_ms_out) return fail(ISINGMC_ERR_INVALID, "device_ms_out is NULL");
+    return run_steps(s, timesteps, betas, beta_stride, nullptr, device_ms_out);
+}
+
+extern "C" int isingmc_get_energies(isingmc_states *s, double *energies_out)
+{
+    if (!s || !energies_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    TRY(use_device(s->g->device));
+    return measure(s, energies_out, nullptr);
+}
+
+extern "C" int isingmc_get_magnetisations(isingmc_states *s, int64_t *mags_out)
+{
+    if (!s || !mags_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    TRY(use_device(s->g->device));
+    return measure(s, nullptr, mags_out);
+}
+
+extern "C" int isingmc_get_packed_states(isingmc_states *s, uint32_t *words_out)
+{
+    if (!s || !words_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    TRY(use_device(s->g->device));
+    if (s->R == 0) return ISINGMC_OK;
+    HIP_TRY(hipMemcpyAsync(words_out, s->d_state, s->R * s->g->state_words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes)
+{
+    if (!s || !states_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (replica_stride_bytes < s->g->nvars) return fail(ISINGMC_ERR_INVALID, "replica stride smaller than nvars");
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    // packed device words -> host, in slabs of replicas, unpacked to bytes by host threads
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(s->R, (size_t(256) << 20) / (g->state_words * 4)));
+    std::vector<uint32_t> words(slab * g->state_words);
+    for (size_t r0 = 0; r0 < s->R; r0 += slab) {
+        const size_t n = std::min(slab, s->R - r0);
+        HIP_TRY(hipMemcpyAsync(words.data(), s->d_state + r0 * g->state_words, n * g->state_words * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        parallel_for(n, [&](size_t i) {
+            unpack_state(g, words.data() + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes);
+        });
+    }
+    return ISINGMC_OK;
+}

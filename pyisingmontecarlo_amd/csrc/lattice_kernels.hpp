@@ -1,0 +1,257 @@
+// Checkerboard Metropolis kernels for a periodic W x H square lattice with uniform |J|
+// (replaces the serial do_time_step loop of lattice.rs:204-207 for recognised lattices).
+//
+// Layout: colour c = (x+y)&1; the colour-c sites of row y are x = 2i + ((y+c)&1);
+// plane c stores row y as wpr = W/64 words, spin i at bit (i&31) of word y*wpr + (i>>5);
+// a replica = plane 0 followed by plane 1.  One thread owns one quad = 4 consecutive words
+// (128 spins) of the plane being updated: one 16-byte load / store per operand.
+//
+// Acceptance: a spin with k satisfied bonds flips always for k <= 2 and with
+// probability exp(-beta 2|J|(2k-4)) for k = 3, 4.  All 128 decisions of a quad are taken
+// bit-sliced: Philox call p (p = 0..7) yields bit-plane p of the spins' 8-bit uniform prefixes,
+// compared MSB-first against the top 8 bits of the 40-bit threshold of each spin's class.  The few
+// spins whose prefix ties the threshold (1/128 of them) are resolved with one 32-bit Philox word
+// each.  Everything is integer: the CPU oracle reproduces the configurations bit for bit.
+#pragma once
+#include "philox.hpp"
+
+namespace isingmc {
+
+struct LatGeom {
+    uint32_t W, H;
+    uint32_t wpr;    // words per colour-row = W / 64
+    uint32_t wpp;    // words per plane = H * wpr
+    uint32_t nquads; // wpp / 4
+};
+
+struct LatThr {
+    uint64_t T3, T4; // floor(exp(-beta dE) 2^40) for k = 3, 4; 2^40 = always accept
+};
+
+constexpr int N_PLANES = 8;
+
+__device__ __forceinline__ uint32_t sel4(uint4 v, uint32_t i)
+{
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// neighbour words of one quad: up / down / centre / side, as the kernel consumes them
+struct QuadNbr {
+    uint32_t up[4], dn[4], ce[4], si[4];
+};
+
+// Loads the 4 own words and the neighbour words of quad Q in plane `colour`.
+template <bool VEC>
+__device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane,
+                                          const uint32_t *__restrict__ oth_plane, const LatGeom &g,
+                                          uint32_t colour, uint32_t Q, uint32_t own[4], QuadNbr &n,
+                                          uint32_t widx[4])
+{
+    if constexpr (VEC) { // wpr % 4 == 0: the quad lies inside one row
+        const uint32_t w0 = 4 * Q;
+        const uint32_t y = w0 / g.wpr, xw = w0 - y * g.wpr;
+        const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
+        const uint32_t row = y * g.wpr;
+        const uint4 o4 = *reinterpret_cast<const uint4 *>(own_plane + w0);
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(oth_plane + w0);
+        const uint4 u4 = *reinterpret_cast<const uint4 *>(oth_plane + yu * g.wpr + xw);
+        const uint4 d4 = *reinterpret_cast<const uint4 *>(oth_plane + yd * g.wpr + xw);
+        own[0] = o4.x; own[1] = o4.y; own[2] = o4.z; own[3] = o4.w;
+        n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
+        n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
+        n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
+        if ((y + colour) & 1) { // horizontal neighbours have compact indices i and i+1
+            const uint32_t nxt = oth_plane[row + (xw + 4 == g.wpr ? 0 : xw + 4)];
+            n.si[0] = (c4.x >> 1) | (c4.y << 31);
+            n.si[1] = (c4.y >> 1) | (c4.z << 31);
+            n.si[2] = (c4.z >> 1) | (c4.w << 31);
+            n.si[3] = (c4.w >> 1) | (nxt << 31);
+        } else { // i-1 and i
+            const uint32_t prv = oth_plane[row + (xw == 0 ? g.wpr : xw) - 1];
+            n.si[0] = (c4.x << 1) | (prv >> 31);
+            n.si[1] = (c4.y << 1) | (c4.x >> 31);
+            n.si[2] = (c4.z << 1) | (c4.y >> 31);
+            n.si[3] = (c4.w << 1) | (c4.z >> 31);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) widx[q] = w0 + q;
+    } else { // narrow lattices (wpr = 1, 2, ...): the quad's words sit in different rows
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t w = 4 * Q + q;
+            const uint32_t y = w / g.wpr, xw = w - y * g.wpr;
+            const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
+            const uint32_t row = y * g.wpr;
+            widx[q] = w;
+            own[q] = own_plane[w];
+            n.ce[q] = oth_plane[w];
+            n.up[q] = oth_plane[yu * g.wpr + xw];
+            n.dn[q] = oth_plane[yd * g.wpr + xw];
+            if ((y + colour) & 1) {
+                const uint32_t nxt = oth_plane[row + (xw + 1 == g.wpr ? 0 : xw + 1)];
+                n.si[q] = (n.ce[q] >> 1) | (nxt << 31);
+            } else {
+                const uint32_t prv = oth_plane[row + (xw == 0 ? g.wpr : xw) - 1];
+                n.si[q] = (n.ce[q] << 1) | (prv >> 31);
+            }
+        }
+    }
+}
+
+// "bond satisfied" masks of the four bonds of each spin of word q.
+// jneg planes hold 1 where J < 0 (ferromagnetic): satisfied = ~(s ^ n) ^ jpos = s ^ n ^ jneg.
+template <bool PMJ>
+__device__ __forceinline__ void bond_masks(const uint32_t own, const QuadNbr &n, int q,
+                                           const uint32_t *__restrict__ jneg, uint32_t wpp,
+                                           uint32_t widx, uint32_t jneg_uniform, uint32_t &a0,
+                                           uint32_t &a1, uint32_t &a2, uint32_t &a3)
+{
+    if constexpr (PMJ) {
+        a0 = own ^ n.up[q] ^ jneg[widx];
+        a1 = own ^ n.dn[q] ^ jneg[wpp + widx];
+        a2 = own ^ n.ce[q] ^ jneg[2 * wpp + widx];
+        a3 = own ^ n.si[q] ^ jneg[3 * wpp + widx];
+    } else {
+        const uint32_t o = own ^ jneg_uniform;
+        a0 = o ^ n.up[q];
+        a1 = o ^ n.dn[q];
+        a2 = o ^ n.ce[q];
+        a3 = o ^ n.si[q];
+    }
+}
+
+template <bool VEC, bool PMJ>
+__global__ __launch_bounds__(256) void lat_sweep_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t,
+    const uint2 *__restrict__ keys, const LatThr thr_uniform, const LatThr *__restrict__ thr_replica,
+    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
+    if (Q >= g.nquads) return;
+
+    const LatThr thr = thr_replica ? thr_replica[r] : thr_uniform;
+    const uint2 key = keys[r];
+    uint32_t *own_plane = state + size_t(r) * 2 * g.wpp + size_t(colour) * g.wpp;
+    const uint32_t *oth_plane = state + size_t(r) * 2 * g.wpp + size_t(1 - colour) * g.wpp;
+    const uint32_t *jn = PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr;
+
+    uint32_t own[4], widx[4];
+    QuadNbr n;
+    load_quad<VEC>(own_plane, oth_plane, g, colour, Q, own, n, widx);
+
+    // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
+    uint32_t eq4[4], lt[4], und[4], le2[4];
+    const bool all3 = (thr.T3 >> 40) != 0, all4 = (thr.T4 >> 40) != 0;
+    const uint32_t hi3 = uint32_t(thr.T3 >> 32) & 0xFFu, hi4 = uint32_t(thr.T4 >> 32) & 0xFFu;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t a0, a1, a2, a3;
+        bond_masks<PMJ>(own[q], n, q, jn, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+        const uint32_t s01 = a0 ^ a1, c01 = a0 & a1, s23 = a2 ^ a3, c23 = a2 & a3;
+        eq4[q] = c01 & c23;
+        const uint32_t eq3 = (c01 & s23) | (c23 & s01);
+        le2[q] = ~(eq3 | eq4[q]);
+        lt[q] = (all3 ? eq3 : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^40: accepted outright
+        und[q] = (eq3 | eq4[q]) & ~lt[q];
+    }
+
+    // 8 bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
+    const uint32_t c0 = Q, c1 = uint32_t(t);
+#pragma unroll
+    for (int p = 0; p < N_PLANES; p++) {
+        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, p), DOM_LAT_SWEEP), key);
+        const uint32_t m3 = 0u - ((hi3 >> (7 - p)) & 1u), m4 = 0u - ((hi4 >> (7 - p)) & 1u);
+        const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t tb = (eq4[q] & m4) | (~eq4[q] & m3);
+            const uint32_t decided = und[q] & (rr[q] ^ tb); // random bit differs from threshold bit
+            lt[q] |= decided & tb;                          // ... and it is the smaller one
+            und[q] ^= decided;
+        }
+    }
+
+    // residual stage: spins whose prefix equals the threshold's top byte draw 32 more bits
+    uint32_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = le2[q] | lt[q];
+    if (und[0] | und[1] | und[2] | und[3]) {
+        const uint32_t lo3 = uint32_t(thr.T3), lo4 = uint32_t(thr.T4);
+        uint32_t nres = 0;
+        uint4 rnd = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t m = und[q];
+            while (m) {
+                const uint32_t b = __ffs(m) - 1;
+                m &= m - 1;
+                if ((nres & 3u) == 0)
+                    rnd = philox4x32_10(
+                        make_uint4(c0, c1, ctr2(t, colour, N_PLANES + (nres >> 2)), DOM_LAT_SWEEP), key);
+                const uint32_t lo = ((eq4[q] >> b) & 1u) ? lo4 : lo3;
+                if (sel4(rnd, nres & 3u) < lo) acc[q] |= 1u << b;
+                nres++;
+            }
+        }
+    }
+
+    if constexpr (VEC) {
+        *reinterpret_cast<uint4 *>(own_plane + widx[0]) =
+            make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) own_plane[widx[q]] = own[q] ^ acc[q];
+    }
+}
+
+// Random initial configuration: word w of plane c = Philox(key, (w>>2, 0, c<<8, "LATI"))[w&3].
+__global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
+                                                       const uint2 *__restrict__ keys,
+                                                       const uint32_t first_replica)
+{
+    const uint32_t r = first_replica + blockIdx.y;
+    const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
+    if (Q >= 2 * g.nquads) return;
+    const uint32_t c = Q >= g.nquads, q = Q - c * g.nquads;
+    const uint4 rnd = philox4x32_10(make_uint4(q, 0, ctr2(0, c, 0), DOM_LAT_INIT), keys[r]);
+    *reinterpret_cast<uint4 *>(state + size_t(r) * 2 * g.wpp + size_t(c) * g.wpp + 4 * size_t(q)) = rnd;
+}
+
+// Full recomputation of the satisfied-bond count and the up-spin count of every replica
+// (get_energy, lattice.rs:208): every bond joins a colour-0 site to a colour-1 site, so the four
+// bonds of the colour-0 sites cover each bond once.  out[2r] += satisfied, out[2r+1] += up spins.
+template <bool VEC, bool PMJ>
+__global__ __launch_bounds__(256) void lat_measure_kernel(
+    const uint32_t *__restrict__ state, const LatGeom g, const uint32_t *__restrict__ jneg,
+    const uint32_t jneg_uniform, unsigned long long *__restrict__ out, const size_t out_stride)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
+    uint32_t sat = 0, up = 0;
+    if (Q < g.nquads) {
+        const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
+        uint32_t own[4], widx[4];
+        QuadNbr n;
+        load_quad<VEC>(p0, p0 + g.wpp, g, 0, Q, own, n, widx);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t a0, a1, a2, a3;
+            bond_masks<PMJ>(own[q], n, q, jneg, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+            sat += __popc(a0) + __popc(a1) + __popc(a2) + __popc(a3);
+            up += __popc(own[q]) + __popc(n.ce[q]);
+        }
+    }
+    // wavefront reduction (64 lanes), then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sat += __shfl_xor(sat, off);
+        up += __shfl_xor(up, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (sat | up)) {
+        atomicAdd(out + size_t(r) * out_stride, (unsigned long long)sat);
+        atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)up);
+    }
+}
+
+} // namespace isingmc

@@ -1,0 +1,35 @@
+// Philox4x32-10 counter-based RNG for gfx950 device code (Salmon et al., SC'11).
+// One call = 10 rounds of two 32x32->64 multiplies (v_mad_u64_u32 / v_mul_hi_u32) + xors; the key
+// schedule is wave-uniform (the key is per replica) and stays on the scalar unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace isingmc {
+
+constexpr uint32_t DOM_LAT_SWEEP = 0x4C415453u; // "LATS"
+constexpr uint32_t DOM_LAT_INIT = 0x4C415449u;  // "LATI"
+constexpr uint32_t DOM_GEN_SWEEP = 0x47454E53u; // "GENS"
+constexpr uint32_t DOM_GEN_INIT = 0x47454E49u;  // "GENI"
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c.x;
+        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c.z;
+        c = make_uint4(uint32_t(p1 >> 32) ^ c.y ^ k.x, uint32_t(p1), uint32_t(p0 >> 32) ^ c.w ^ k.y,
+                       uint32_t(p0));
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// counter word 2: (t >> 32) in the top 16 bits, colour in bits 8..15, call index in bits 0..7
+__device__ __forceinline__ uint32_t ctr2(uint64_t t, uint32_t colour, uint32_t call)
+{
+    return (uint32_t((t >> 32) & 0xFFFFu) << 16) | ((colour & 0xFFu) << 8) | (call & 0xFFu);
+}
+
+} // namespace isingmc

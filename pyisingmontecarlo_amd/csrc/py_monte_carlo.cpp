@@ -1,0 +1,509 @@
+// Host shim with the Python surface of the reference's pyo3 module `py_monte_carlo`
+// (src/lib.rs:14-22) for the classical hot path: classes Lattice (src/lattice.rs:27-470) and
+// ClassicIsing (src/classicising.rs:11-180).  Same method names, positional order, keyword names,
+// None-defaults, return tuple order, dtypes (float64 / bool) and ValueError messages.  The reference
+// host is Rust/pyo3; no Rust toolchain exists in this image, so the shim is C++/pybind11 over the C
+// ABI of include/isingmc.h -- exactly the calls a pyo3 maintainer would bind.
+// All Monte-Carlo work happens in libisingmc.so's HIP kernels; nothing here computes a spin flip.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstdlib>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "isingmc.h"
+
+namespace py = pybind11;
+
+using Edge = std::pair<std::pair<size_t, size_t>, double>;
+
+namespace {
+
+void check(int rc)
+{
+    if (rc == ISINGMC_OK) return;
+    const std::string msg = isingmc_last_error();
+    if (rc == ISINGMC_ERR_INVALID) throw py::value_error(msg);
+    if (rc == ISINGMC_ERR_ALLOC) throw std::bad_alloc();
+    throw std::runtime_error(msg);
+}
+
+int default_device()
+{
+    if (const char *d = std::getenv("ISINGMC_DEVICE")) return std::atoi(d);
+    if (const char *lr = std::getenv("LOCAL_RANK")) { // one process per GPU under torchrun
+        int count = 0;
+        if (isingmc_device_count(&count) == ISINGMC_OK && std::atoi(lr) < count) return std::atoi(lr);
+    }
+    return 0;
+}
+
+bool compat_anneal_bug()
+{
+    const char *e = std::getenv("ISINGMC_COMPAT_ANNEAL_BUG");
+    return e && e[0] && e[0] != '0';
+}
+
+struct GraphHandle {
+    isingmc_graph *g = nullptr;
+    ~GraphHandle() { isingmc_graph_destroy(g); }
+};
+
+struct StatesHandle {
+    isingmc_states *s = nullptr;
+    std::shared_ptr<GraphHandle> graph; // the graph must outlive the states
+    ~StatesHandle() { isingmc_states_destroy(s); }
+};
+
+struct EdgeArrays {
+    std::vector<uint64_t> a, b;
+    std::vector<double> j;
+    size_t nvars = 0;
+};
+
+EdgeArrays split_edges(const std::vector<Edge> &edges)
+{
+    EdgeArrays E;
+    E.a.reserve(edges.size());
+    E.b.reserve(edges.size());
+    E.j.reserve(edges.size());
+    for (const auto &e : edges) {
+        E.a.push_back(e.first.first);
+        E.b.push_back(e.first.second);
+        E.j.push_back(e.second);
+        E.nvars = std::max(E.nvars, std::max(e.first.first, e.first.second) + 1); // lattice.rs:51-55
+    }
+    return E;
+}
+
+std::shared_ptr<GraphHandle> make_graph(const EdgeArrays &E, const std::vector<double> *biases, int device,
+                                        bool force_general)
+{
+    auto h = std::make_shared<GraphHandle>();
+    py::gil_scoped_release nogil;
+    check(isingmc_graph_create(E.a.data(), E.b.data(), E.j.data(), E.a.size(), E.nvars,
+                               biases ? biases->data() : nullptr, device,
+                               force_general ? ISINGMC_FLAG_FORCE_GENERAL : 0u, &h->g));
+    return h;
+}
+
+std::vector<uint8_t> to_bytes(const std::vector<bool> &v)
+{
+    return std::vector<uint8_t>(v.begin(), v.end());
+}
+
+using Range = std::optional<std::pair<size_t, size_t>>;
+
+// ------------------------------------------------------------------------------------------------
+// Lattice (src/lattice.rs:27-470, classical methods)
+// ------------------------------------------------------------------------------------------------
+class Lattice {
+public:
+    Lattice(const std::vector<Edge> &edges, std::optional<uint64_t> seed_gen, std::optional<bool> use_allocator)
+        : E_(std::make_shared<EdgeArrays>(split_edges(edges))), seed_gen_(seed_gen),
+          use_allocator_(use_allocator.value_or(true)), device_(default_device())
+    {
+        if (edges.empty()) throw py::value_error("Must supply some edges for graph"); // lattice.rs:70-72
+    }
+
+    // extension: numpy ingest without building 10^7 Python tuples
+    static Lattice from_arrays(py::array_t<uint64_t, py::array::c_style | py::array::forcecast> a,
+                               py::array_t<uint64_t, py::array::c_style | py::array::forcecast> b,
+                               py::array_t<double, py::array::c_style | py::array::forcecast> j,
+                               std::optional<uint64_t> seed_gen)
+    {
+        if (a.ndim() != 1 || a.size() != b.size() || a.size() != j.size())
+            throw py::value_error("edge arrays must be 1-d and of equal length");
+        if (a.size() == 0) throw py::value_error("Must supply some edges for graph");
+        Lattice L;
+        auto E = std::make_shared<EdgeArrays>();
+        E->a.assign(a.data(), a.data() + a.size());
+        E->b.assign(b.data(), b.data() + b.size());
+        E->j.assign(j.data(), j.data() + j.size());
+        for (ssize_t k = 0; k < a.size(); k++) E->nvars = std::max<size_t>(E->nvars, std::max(E->a[k], E->b[k]) + 1);
+        L.E_ = E;
+        L.seed_gen_ = seed_gen;
+        L.device_ = default_device();
+        return L;
+    }
+
+    void set_seed_gen(std::optional<uint64_t> seed_gen) { seed_gen_ = seed_gen; } // lattice.rs:78-80
+
+    std::vector<uint64_t> make_seeds(size_t num_experiments) const // lattice.rs:83-91
+    {
+        std::vector<uint64_t> seeds(num_experiments);
+        check(isingmc_host_make_seeds(seed_gen_.has_value(), seed_gen_.value_or(0), num_experiments, seeds.data()));
+        return seeds;
+    }
+
+    void set_enable_rvb_update(bool v) { enable_rvb_ = v; }      // lattice.rs:94-96 (QMC only; stored)
+    void set_enable_heatbath_update(bool v) { enable_heatbath_ = v; } // lattice.rs:99-101
+
+    void set_individual_bias(size_t var, double bias) // lattice.rs:104-126
+    {
+        if (var >= E_->nvars)
+            throw py::value_error("Index out of bounds: variable " + std::to_string(var) + " out of " +
+                                  std::to_string(E_->nvars));
+        if (biases_.empty()) biases_.assign(E_->nvars, global_bias_);
+        biases_[var] = bias;
+        graph_.reset();
+    }
+
+    void set_global_bias(double bias) // lattice.rs:129-131
+    {
+        biases_.clear();
+        global_bias_ = bias;
+        graph_.reset();
+    }
+
+    void set_transverse_field(double transverse) // lattice.rs:134-146
+    {
+        if (transverse > 0.0) transverse_ = transverse;
+        else if (transverse == 0.0) transverse_.reset();
+        else throw py::value_error("Transverse field must be positive");
+    }
+
+    void set_initial_state(const std::vector<bool> &initial_state) // lattice.rs:149-161
+    {
+        if (initial_state.size() == E_->nvars) initial_state_ = to_bytes(initial_state);
+        else if (initial_state.empty()) initial_state_.clear();
+        else throw py::value_error("Initial state must be of the same size as biases, or 0.");
+    }
+
+    // extensions: device ordinal, and forcing the general edge-list path (BASELINE config c5)
+    void set_device(int device) { device_ = device; graph_.reset(); }
+    void set_force_general_path(bool v) { force_general_ = v; graph_.reset(); }
+    py::dict engine_info()
+    {
+        isingmc_graph_info_t info;
+        check(isingmc_graph_info(graph()->g, &info));
+        py::dict d;
+        d["kind"] = info.kind == ISINGMC_KIND_LATTICE2D ? "lattice2d" : "general";
+        d["device"] = info.device;
+        d["nvars"] = info.nvars;
+        d["width"] = info.width;
+        d["height"] = info.height;
+        d["n_colours"] = info.n_colours;
+        d["uniform_sign"] = bool(info.uniform_sign);
+        return d;
+    }
+
+    // lattice.rs:171-221
+    py::tuple run_monte_carlo(double beta, size_t timesteps, size_t num_experiments, std::optional<bool>,
+                              std::optional<bool>, Range replica_range)
+    {
+        require_classical();
+        auto st = fresh_states(num_experiments, replica_range);
+        const size_t R = count(st);
+        py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R)});
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
+        {
+            py::gil_scoped_release nogil;
+            check(isingmc_do_time_steps(st->s, timesteps, &beta, 0, nullptr));
+            check(isingmc_get_energies(st->s, energies.mutable_data()));
+            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
+        }
+        return py::make_tuple(energies, states);
+    }
+
+    // lattice.rs:231-299
+    py::tuple run_monte_carlo_sampling(double beta, size_t timesteps, size_t num_experiments, std::optional<bool>,
+                                       std::optional<size_t> thermalization_time, std::optional<size_t> sampling_freq,
+                                       std::optional<bool>, Range replica_range)
+    {
+        require_classical();
+        const size_t therm = thermalization_time.value_or(0), freq = sampling_freq.value_or(1);
+        if (freq == 0) throw py::value_error("sampling_freq must be positive");
+        const size_t S = timesteps / freq; // lattice.rs:247
+        auto st = fresh_states(num_experiments, replica_range);
+        const size_t R = count(st), N = E_->nvars;
+        py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(S)});
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(S), ssize_t(N)});
+        {
+            py::gil_scoped_release nogil;
+            sample_into(st->s, beta, therm, freq, S, R, N, energies.mutable_data(),
+                        reinterpret_cast<uint8_t *>(states.mutable_data()));
+        }
+        return py::make_tuple(energies, states);
+    }
+
+    // lattice.rs:309-385
+    py::tuple run_monte_carlo_annealing(const std::vector<std::pair<size_t, double>> &betas, size_t timesteps,
+                                        size_t num_experiments, std::optional<bool>, std::optional<bool>,
+                                        Range replica_range)
+    {
+        require_classical();
+        const std::vector<double> schedule = expand(betas, timesteps);
+        auto st = fresh_states(num_experiments, replica_range);
+        const size_t R = count(st);
+        py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R)});
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
+        {
+            py::gil_scoped_release nogil;
+            check(isingmc_do_time_steps(st->s, timesteps, schedule.data(), 1, nullptr));
+            check(isingmc_get_energies(st->s, energies.mutable_data()));
+            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
+        }
+        return py::make_tuple(energies, states);
+    }
+
+    // lattice.rs:395-470
+    py::tuple run_monte_carlo_annealing_and_get_energies(const std::vector<std::pair<size_t, double>> &betas,
+                                                         size_t timesteps, size_t num_experiments,
+                                                         std::optional<bool>, std::optional<bool>, Range replica_range)
+    {
+        require_classical();
+        const std::vector<double> schedule = expand(betas, timesteps);
+        auto st = fresh_states(num_experiments, replica_range);
+        const size_t R = count(st);
+        py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(timesteps)});
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
+        {
+            py::gil_scoped_release nogil;
+            check(isingmc_do_time_steps(st->s, timesteps, schedule.data(), 1, energies.mutable_data()));
+            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
+        }
+        return py::make_tuple(energies, states);
+    }
+
+    Lattice clone() const { return *this; } // lattice.rs:1038-1040 (the immutable device graph is shared)
+
+    static void sample_into(isingmc_states *s, double beta, size_t therm, size_t freq, size_t S, size_t R, size_t N,
+                            double *energies, uint8_t *states)
+    {
+        check(isingmc_do_time_steps(s, therm, &beta, 0, nullptr)); // lattice.rs:271-273
+        std::vector<double> e(R);
+        for (size_t k = 0; k < S; k++) { // lattice.rs:274-287: freq steps, then record state + energy
+            check(isingmc_do_time_steps(s, freq, &beta, 0, nullptr));
+            check(isingmc_get_states(s, states + k * N, S * N));
+            check(isingmc_get_energies(s, e.data()));
+            for (size_t r = 0; r < R; r++) energies[r * S + k] = e[r];
+        }
+    }
+
+private:
+    Lattice() = default;
+
+    void require_classical() const
+    {
+        if (transverse_) // lattice.rs:217-219
+            throw py::value_error("Cannot run classic monte carlo with transverse field");
+    }
+
+    std::shared_ptr<GraphHandle> graph()
+    {
+        if (!graph_) {
+            std::vector<double> b;
+            const std::vector<double> *bp = nullptr;
+            if (!biases_.empty()) bp = &biases_;
+            else if (global_bias_ != 0.0) { b.assign(E_->nvars, global_bias_); bp = &b; } // lattice.rs:186-189
+            graph_ = make_graph(*E_, bp, device_, force_general_);
+        }
+        return graph_;
+    }
+
+    // R x { seed -> rng; GraphState::new; set_state(initial) }  (lattice.rs:191-203).  replica_range
+    // (extension) keeps only experiments [lo, hi) of the num_experiments seeds: one shard per GPU/rank.
+    std::shared_ptr<StatesHandle> fresh_states(size_t num_experiments, const Range &range)
+    {
+        std::vector<uint64_t> seeds = make_seeds(num_experiments);
+        size_t lo = 0, hi = num_experiments;
+        if (range) {
+            lo = range->first;
+            hi = range->second;
+            if (lo > hi || hi > num_experiments) throw py::value_error("replica_range out of bounds");
+        }
+        auto st = std::make_shared<StatesHandle>();
+        st->graph = graph();
+        py::gil_scoped_release nogil;
+        check(isingmc_states_create(st->graph->g, hi - lo, seeds.data() + lo,
+                                    initial_state_.empty() ? nullptr : initial_state_.data(), &st->s));
+        return st;
+    }
+
+    static size_t count(const std::shared_ptr<StatesHandle> &st) { return isingmc_states_count(st->s); }
+
+    static std::vector<double> expand(const std::vector<std::pair<size_t, double>> &betas, size_t timesteps)
+    {
+        std::vector<uint64_t> t;
+        std::vector<double> b;
+        for (const auto &s : betas) { t.push_back(s.first); b.push_back(s.second); }
+        std::vector<double> out(timesteps);
+        check(isingmc_host_expand_schedule(t.data(), b.data(), t.size(), timesteps, compat_anneal_bug(), out.data()));
+        return out;
+    }
+
+    std::shared_ptr<EdgeArrays> E_;
+    std::vector<double> biases_; // empty = BiasType::Global(global_bias_)
+    double global_bias_ = 0.0;
+    std::optional<double> transverse_;
+    std::vector<uint8_t> initial_state_;
+    bool enable_rvb_ = false, enable_heatbath_ = false;
+    std::optional<uint64_t> seed_gen_;
+    bool use_allocator_ = true;
+    int device_ = 0;
+    bool force_general_ = false;
+    std::shared_ptr<GraphHandle> graph_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// ClassicIsing (src/classicising.rs:11-180): replicas persist on the device between calls
+// ------------------------------------------------------------------------------------------------
+class ClassicIsing {
+public:
+    ClassicIsing(const std::vector<Edge> &edges, std::optional<double> longitudinal,
+                 std::optional<size_t> num_experiments, std::optional<uint64_t> seed, std::optional<bool> use_basic_moves)
+        : E_(split_edges(edges)), longitudinal_(longitudinal.value_or(0.0)),
+          use_basic_moves_(use_basic_moves.value_or(false))
+    {
+        // the reference unwraps None here and aborts the process (classicising.rs:34-39)
+        if (edges.empty()) throw py::value_error("Must supply some edges for graph");
+        if (seed) master_seed_ = *seed;
+        else check(isingmc_host_make_seeds(0, 0, 1, &master_seed_)); // SmallRng::from_entropy()
+        std::vector<double> bias;
+        if (longitudinal_ != 0.0) bias.assign(E_.nvars, longitudinal_); // classicising.rs:69
+        graph_ = make_graph(E_, bias.empty() ? nullptr : &bias, default_device(), false);
+        st_ = std::make_shared<StatesHandle>();
+        st_->graph = graph_;
+        check(isingmc_states_create(graph_->g, 0, nullptr, nullptr, &st_->s));
+        const size_t n = num_experiments.value_or(1);
+        for (size_t i = 0; i < n; i++) add_graph(std::nullopt, std::nullopt);
+    }
+
+    // classicising.rs:62-79: seed = self.rng.gen(); GraphState::new / new_with_state_and_rng
+    void add_graph(std::optional<std::vector<bool>> initial_state, std::optional<bool>)
+    {
+        std::vector<uint8_t> ini;
+        if (initial_state) {
+            if (initial_state->size() != E_.nvars)
+                throw py::value_error("Initial state must be of the same size as biases, or 0.");
+            ini = to_bytes(*initial_state);
+        }
+        drawn_.resize(drawn_.size() + 1);
+        check(isingmc_host_make_seeds(1, master_seed_, drawn_.size(), drawn_.data())); // n-th draw of the master rng
+        py::gil_scoped_release nogil;
+        check(isingmc_states_append(st_->s, drawn_.back(), initial_state ? ini.data() : nullptr));
+    }
+
+    // classicising.rs:88-110
+    void run_monte_carlo(double beta, size_t timesteps, std::optional<size_t> nspinupdates, std::optional<size_t>,
+                         std::optional<size_t>, std::optional<bool>)
+    {
+        const size_t mult = sweeps_per_timestep(nspinupdates);
+        py::gil_scoped_release nogil;
+        check(isingmc_do_time_steps(st_->s, timesteps * mult, &beta, 0, nullptr));
+    }
+
+    // classicising.rs:119-179
+    py::tuple run_monte_carlo_sampling(double beta, size_t timesteps, std::optional<size_t> nspinupdates,
+                                       std::optional<size_t>, std::optional<size_t>, std::optional<bool>,
+                                       std::optional<size_t> thermalization_time, std::optional<size_t> sampling_freq)
+    {
+        const size_t mult = sweeps_per_timestep(nspinupdates);
+        const size_t therm = thermalization_time.value_or(0), freq = sampling_freq.value_or(1);
+        if (freq == 0) throw py::value_error("sampling_freq must be positive");
+        const size_t S = timesteps / freq, R = isingmc_states_count(st_->s), N = E_.nvars;
+        py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(S)});
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(S), ssize_t(N)});
+        {
+            py::gil_scoped_release nogil;
+            Lattice::sample_into(st_->s, beta, therm * mult, freq * mult, S, R, N, energies.mutable_data(),
+                                 reinterpret_cast<uint8_t *>(states.mutable_data()));
+        }
+        return py::make_tuple(energies, states);
+    }
+
+    // extensions: read the persistent replicas without advancing them
+    py::array_t<double> get_energies()
+    {
+        py::array_t<double> e(std::vector<ssize_t>{ssize_t(isingmc_states_count(st_->s))});
+        check(isingmc_get_energies(st_->s, e.mutable_data()));
+        return e;
+    }
+    py::array_t<bool> get_states()
+    {
+        py::array_t<bool> s(std::vector<ssize_t>{ssize_t(isingmc_states_count(st_->s)), ssize_t(E_.nvars)});
+        check(isingmc_get_states(st_->s, reinterpret_cast<uint8_t *>(s.mutable_data()), E_.nvars));
+        return s;
+    }
+    size_t get_num_graphs() const { return isingmc_states_count(st_->s); }
+
+private:
+    // nspinupdates = single-spin attempts per timestep (crate default: nvars).  A sweep is nvars
+    // attempts, so only whole multiples can be honoured.
+    size_t sweeps_per_timestep(const std::optional<size_t> &nspinupdates) const
+    {
+        if (!nspinupdates) return 1;
+        if (*nspinupdates == 0 || *nspinupdates % E_.nvars != 0)
+            throw py::value_error("nspinupdates must be a positive multiple of the number of variables (" +
+                                  std::to_string(E_.nvars) + "): one timestep is made of whole sweeps");
+        return *nspinupdates / E_.nvars;
+    }
+
+    EdgeArrays E_;
+    double longitudinal_;
+    bool use_basic_moves_; // stored, never read -- as in the reference (classicising.rs:45,54)
+    uint64_t master_seed_ = 0;
+    std::vector<uint64_t> drawn_;
+    std::shared_ptr<GraphHandle> graph_;
+    std::shared_ptr<StatesHandle> st_;
+};
+
+} // namespace
+
+PYBIND11_MODULE(_py_monte_carlo, m)
+{
+    m.doc() = "MI355X-native classical Ising Metropolis engine behind the py_monte_carlo API";
+    using namespace py::literals;
+
+    py::class_<Lattice>(m, "Lattice")
+        .def(py::init<const std::vector<Edge> &, std::optional<uint64_t>, std::optional<bool>>(), "edges"_a,
+             "seed_gen"_a = py::none(), "use_allocator"_a = py::none())
+        .def_static("from_arrays", &Lattice::from_arrays, "edge_a"_a, "edge_b"_a, "edge_j"_a, "seed_gen"_a = py::none())
+        .def("set_seed_gen", &Lattice::set_seed_gen, "seed_gen"_a = py::none())
+        .def("make_seeds", &Lattice::make_seeds, "num_experiments"_a)
+        .def("set_enable_rvb_update", &Lattice::set_enable_rvb_update, "enable_updates"_a)
+        .def("set_enable_heatbath_update", &Lattice::set_enable_heatbath_update, "enable_heatbath"_a)
+        .def("set_individual_bias", &Lattice::set_individual_bias, "var"_a, "bias"_a)
+        .def("set_global_bias", &Lattice::set_global_bias, "bias"_a)
+        .def("set_transverse_field", &Lattice::set_transverse_field, "transverse"_a)
+        .def("set_initial_state", &Lattice::set_initial_state, "initial_state"_a)
+        .def("set_device", &Lattice::set_device, "device"_a)
+        .def("set_force_general_path", &Lattice::set_force_general_path, "force"_a)
+        .def("engine_info", &Lattice::engine_info)
+        .def("run_monte_carlo", &Lattice::run_monte_carlo, "beta"_a, "timesteps"_a, "num_experiments"_a,
+             "only_basic_moves"_a = py::none(), "edge_move_importance_sampling"_a = py::none(),
+             "replica_range"_a = py::none())
+        .def("run_monte_carlo_sampling", &Lattice::run_monte_carlo_sampling, "beta"_a, "timesteps"_a,
+             "num_experiments"_a, "only_basic_moves"_a = py::none(), "thermalization_time"_a = py::none(),
+             "sampling_freq"_a = py::none(), "edge_move_importance_sampling"_a = py::none(),
+             "replica_range"_a = py::none())
+        .def("run_monte_carlo_annealing", &Lattice::run_monte_carlo_annealing, "betas"_a, "timesteps"_a,
+             "num_experiments"_a, "only_basic_moves"_a = py::none(), "edge_move_importance_sampling"_a = py::none(),
+             "replica_range"_a = py::none())
+        .def("run_monte_carlo_annealing_and_get_energies", &Lattice::run_monte_carlo_annealing_and_get_energies,
+             "betas"_a, "timesteps"_a, "num_experiments"_a, "only_basic_moves"_a = py::none(),
+             "edge_move_importance_sampling"_a = py::none(), "replica_range"_a = py::none())
+        .def("clone", &Lattice::clone);
+
+    py::class_<ClassicIsing>(m, "ClassicIsing")
+        .def(py::init<const std::vector<Edge> &, std::optional<double>, std::optional<size_t>, std::optional<uint64_t>,
+                      std::optional<bool>>(),
+             "edges"_a, "longitudinal"_a = py::none(), "num_experiments"_a = py::none(), "seed"_a = py::none(),
+             "use_basic_moves"_a = py::none())
+        .def("add_graph", &ClassicIsing::add_graph, "initial_state"_a = py::none(),
+             "edge_move_importance_sampling"_a = py::none())
+        .def("run_monte_carlo", &ClassicIsing::run_monte_carlo, "beta"_a, "timesteps"_a, "nspinupdates"_a = py::none(),
+             "nedgeupdates"_a = py::none(), "nwormupdates"_a = py::none(), "only_basic_moves"_a = py::none())
+        .def("run_monte_carlo_sampling", &ClassicIsing::run_monte_carlo_sampling, "beta"_a, "timesteps"_a,
+             "nspinupdates"_a = py::none(), "nedgeupdates"_a = py::none(), "nwormupdates"_a = py::none(),
+             "only_basic_moves"_a = py::none(), "thermalization_time"_a = py::none(), "sampling_freq"_a = py::none())
+        .def("get_energies", &ClassicIsing::get_energies)
+        .def("get_states", &ClassicIsing::get_states)
+        .def("get_num_graphs", &ClassicIsing::get_num_graphs);
+}

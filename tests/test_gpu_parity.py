@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Integer / bit work (spin configurations, lattice energies) must match BIT FOR BIT; f64 energies of the
+general path within 1e-9 relative (the reduction order differs, nothing else).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = np.array([0x0123456789ABCDEF, 42, 2**64 - 1], dtype=np.uint64)
+
+
+def _lattice_case(capi, oracle, exact, W, H, J, beta, T, rng=None, per_step=False):
+    ea, eb, ej = exact.square_lattice_edges(W, H, J, rng)
+    g = capi.Graph(ea, eb, ej)
+    assert g.kind == capi.KIND_LATTICE2D, "recogniser must take the checkerboard path"
+    st = capi.States(g, SEEDS)
+    if rng is None:
+        lat = oracle.Lat(W, H, abs(J), int(J > 0))
+    else:
+        jr = (ej[0::2] > 0).astype(np.uint8)
+        jd = (ej[1::2] > 0).astype(np.uint8)
+        lat = oracle.Lat(W, H, abs(J), 0, jr, jd)
+    ref = [lat.init(s) for s in SEEDS]
+    np.testing.assert_array_equal(st.packed(), np.stack(ref), err_msg="initial state")
+    eps = st.do_time_steps(T, beta, per_step_energies=per_step)
+    ref_eps = np.zeros((len(SEEDS), T))
+    for r, s in enumerate(SEEDS):
+        for t in range(T):
+            lat.sweep(ref[r], s, t, beta)
+            ref_eps[r, t] = lat.energy_mag(ref[r])[0]
+    np.testing.assert_array_equal(st.packed(), np.stack(ref), err_msg="state after sweeps")
+    if per_step:
+        np.testing.assert_array_equal(eps, ref_eps)
+    em = [lat.energy_mag(x) for x in ref]
+    np.testing.assert_array_equal(st.energies(), [e for e, _ in em])
+    np.testing.assert_array_equal(st.magnetisations(), [m for _, m in em])
+    spins = st.states()
+    for r in range(len(SEEDS)):
+        np.testing.assert_array_equal(spins[r].astype(np.uint8), lat.unpack(ref[r]))
+        # K1: energy recomputed from the returned configuration (README.md:45-46)
+        e_k1 = oracle.energy(ea, eb, ej, W * H, spins[r])
+        if float(J).is_integer():
+            assert st.energies()[r] == e_k1
+        else:  # the oracle sums 2N non-integer terms sequentially; the engine returns |J| x integer
+            np.testing.assert_allclose(st.energies()[r], e_k1, rtol=1e-9)
+    assert st.timestep == T
+    return st
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (128, 32), (256, 64), (512, 16), (64, 4)])
+@pytest.mark.parametrize("beta", [0.4407, 0.0, 1.5])
+def test_lattice_uniform_ferro_bit_exact(capi, oracle, exact, W, H, beta):
+    _lattice_case(capi, oracle, exact, W, H, -1.0, beta, T=6)
+
+
+def test_lattice_uniform_antiferro_bit_exact(capi, oracle, exact):
+    _lattice_case(capi, oracle, exact, 256, 32, 1.0, 0.6, T=6)
+
+
+def test_lattice_scaled_coupling_bit_exact(capi, oracle, exact):
+    _lattice_case(capi, oracle, exact, 128, 64, -0.37, 1.1, T=6)
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (256, 32)])
+def test_lattice_pm_j_bit_exact(capi, oracle, exact, W, H):
+    _lattice_case(capi, oracle, exact, W, H, 1.0, 0.8, T=6, rng=np.random.default_rng(2024), per_step=True)
+
+
+def test_lattice_negative_beta_always_accepts(capi, oracle, exact):
+    _lattice_case(capi, oracle, exact, 64, 64, -1.0, -0.3, T=3)
+
+
+def test_lattice_per_step_energies(capi, oracle, exact):
+    _lattice_case(capi, oracle, exact, 256, 16, -1.0, 0.5, T=9, per_step=True)
+
+
+def test_lattice_initial_state_and_set_state(capi, oracle, exact):
+    W, H = 128, 16
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    rng = np.random.default_rng(7)
+    ini = rng.integers(0, 2, W * H).astype(np.uint8)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, SEEDS, initial_state=ini)
+    lat = oracle.Lat(W, H)
+    for r in range(3):
+        np.testing.assert_array_equal(st.packed()[r], lat.pack(ini))
+    other = rng.integers(0, 2, W * H).astype(np.uint8)
+    st.set_state(1, other)
+    np.testing.assert_array_equal(st.states()[1].astype(np.uint8), other)
+    np.testing.assert_array_equal(st.states()[2].astype(np.uint8), ini)
+    st.do_time_steps(4, 0.7)
+    ref = lat.pack(other)
+    for t in range(4):
+        lat.sweep(ref, SEEDS[1], t, 0.7)
+    np.testing.assert_array_equal(st.packed()[1], ref)
+
+
+def test_lattice_per_replica_betas(capi, oracle, exact):
+    W, H = 256, 16
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, SEEDS)
+    betas = [0.2, 0.4407, 0.9]
+    st.set_betas(betas)
+    st.do_time_steps(5)
+    lat = oracle.Lat(W, H)
+    for r, s in enumerate(SEEDS):
+        ref = lat.init(s)
+        for t in range(5):
+            lat.sweep(ref, s, t, betas[r])
+        np.testing.assert_array_equal(st.packed()[r], ref)
+
+
+def test_lattice_append_and_continue(capi, oracle, exact):
+    """Timesteps continue across calls; an appended replica joins at the current timestep."""
+    W, H = 64, 64
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, SEEDS[:2])
+    st.do_time_steps(3, 0.4)
+    st.append(int(SEEDS[2]))
+    st.do_time_steps(2, 0.4)
+    lat = oracle.Lat(W, H)
+    for r, s in enumerate(SEEDS):
+        ref = lat.init(s)
+        for t in (range(5) if r < 2 else range(3, 5)):
+            lat.sweep(ref, s, t, 0.4)
+        np.testing.assert_array_equal(st.packed()[r], ref)
+
+
+def _general_case(capi, oracle, ea, eb, ej, nvars, beta, T, biases=None, force_general=False, initial=None):
+    g = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases, force_general=force_general)
+    assert g.kind == capi.KIND_GENERAL
+    st = capi.States(g, SEEDS, initial_state=initial)
+    eps = st.do_time_steps(T, beta, per_step_energies=True)
+    spins = st.states()
+    energies = st.energies()
+    for r, s in enumerate(SEEDS):
+        betas = [beta] * T if np.ndim(beta) == 0 else beta
+        e_ref, s_ref, eps_ref = oracle.gen_run(ea, eb, ej, nvars, s, betas, biases=biases, initial=initial,
+                                               per_step=True)
+        np.testing.assert_array_equal(spins[r].astype(np.uint8), s_ref, err_msg=f"replica {r}")
+        np.testing.assert_allclose(eps[r], eps_ref, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(energies[r], e_ref, rtol=1e-9, atol=1e-9)
+    return st
+
+
+def test_general_small_lattice_16x16(capi, oracle, exact):
+    """BASELINE config c1's lattice (16x16, beta=0.3): not a multiple of 64 wide -> general path."""
+    ea, eb, ej = exact.square_lattice_edges(16, 16, -1.0)
+    _general_case(capi, oracle, ea, eb, ej, 256, 0.3, T=25)
+
+
+def test_general_random_real_couplings_with_bias(capi, oracle):
+    rng = np.random.default_rng(11)
+    n, m = 300, 900
+    ea = rng.integers(0, n, m).astype(np.uint64)
+    eb = rng.integers(0, n, m).astype(np.uint64)  # includes a few self loops and duplicate edges
+    ej = rng.normal(size=m)
+    biases = rng.normal(size=n) * 0.5
+    _general_case(capi, oracle, ea, eb, ej, n, 0.7, T=20, biases=biases)
+
+
+def test_general_isolated_sites_and_initial_state(capi, oracle):
+    """nvars = max index + 1 (lattice.rs:51-55): unused indices are still spins."""
+    ea = np.array([0, 5, 9], dtype=np.uint64)
+    eb = np.array([5, 9, 40], dtype=np.uint64)
+    ej = np.array([1.0, -2.0, 0.5])
+    ini = (np.arange(41) % 3 == 0).astype(np.uint8)
+    _general_case(capi, oracle, ea, eb, ej, 41, 0.9, T=12, initial=ini)
+
+
+def test_general_cubic_forced(capi, oracle, exact):
+    """BASELINE config c5's shape (3-d cubic through the general path), small."""
+    ea, eb, ej = exact.cubic_lattice_edges(8, -1.0)
+    _general_case(capi, oracle, ea, eb, ej, 512, 0.2217, T=10, force_general=True)
+
+
+def test_general_forced_on_recognisable_lattice(capi, oracle, exact):
+    ea, eb, ej = exact.square_lattice_edges(64, 8, -1.0)
+    _general_case(capi, oracle, ea, eb, ej, 512, 0.5, T=8, force_general=True)
+
+
+def test_general_annealing_schedule(capi, oracle, exact):
+    ea, eb, ej = exact.square_lattice_edges(12, 10, 1.0, np.random.default_rng(5))
+    betas = capi.expand_schedule([(0, 0.1), (10, 2.0)], 15)
+    _general_case(capi, oracle, ea, eb, ej, 120, betas, T=15)
+
+
+def test_readme_three_spin_chain_energies(capi, oracle):
+    """README.md:50-53 edge list; hand-checked energies."""
+    ea, eb, ej = np.array([0, 1], dtype=np.uint64), np.array([1, 2], dtype=np.uint64), np.array([1.0, -1.0])
+    g = capi.Graph(ea, eb, ej)
+    for state, e in [((1, 1, 1), 0.0), ((1, 0, 1), 0.0), ((1, 0, 0), -2.0), ((1, 1, 0), 2.0)]:
+        st = capi.States(g, SEEDS[:1], initial_state=np.array(state, dtype=np.uint8))
+        assert st.energies()[0] == e
+        assert oracle.energy(ea, eb, ej, 3, np.array(state, dtype=np.uint8)) == e
