@@ -42,6 +42,7 @@
  * (crate-internal), chosen as -h s.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -253,6 +254,48 @@ void orc_ref_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const d
                     energies_per_step ? energies_per_step + r * timesteps : NULL, n_edges, ea, eb,
                     ej);
     adj_free(&A);
+}
+
+/*
+ * Timed variant for bench.py's cpu_baseline leg: the same R chains on `threads` OpenMP threads,
+ * constant beta, no outputs kept; *seconds_out = wall time of the sweep loop only (adjacency
+ * construction and the random start are excluded, as on the GPU side).  Returns a checksum of the
+ * final configurations so the work cannot be optimised away.
+ */
+uint64_t orc_ref_bench(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                       size_t nvars, const uint64_t *seeds, size_t R, double beta,
+                       size_t timesteps, int threads, double *seconds_out)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+    uint8_t *states = malloc(R * nvars);
+    xoshiro *rngs = malloc(R * sizeof(xoshiro));
+    for (size_t r = 0; r < R; r++) {
+        xo_seed_from_u64(&rngs[r], seeds[r]);
+        for (size_t i = 0; i < nvars; i++) states[r * nvars + i] = (uint8_t)xo_bool(&rngs[r]);
+    }
+    double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (size_t r = 0; r < R; r++) {
+        uint8_t *state = states + r * nvars;
+        xoshiro g = rngs[r];
+        for (size_t t = 0; t < timesteps; t++)
+            for (size_t a = 0; a < nvars; a++) {
+                size_t i = (size_t)xo_below(&g, nvars);
+                double si = state[i] ? 1.0 : -1.0;
+                double field = 0.0;
+                for (size_t e = A.ptr[i]; e < A.ptr[i + 1]; e++)
+                    field += A.w[e] * (state[A.nbr[e]] ? 1.0 : -1.0);
+                double dE = 2.0 * si * (0.0 - field);
+                if (dE <= 0.0 || xo_f64(&g) < exp(-beta * dE)) state[i] = !state[i];
+            }
+    }
+    *seconds_out = omp_get_wtime() - t0;
+    uint64_t sum = 0;
+    for (size_t k = 0; k < R * nvars; k++) sum += states[k];
+    free(states); free(rngs);
+    adj_free(&A);
+    return sum;
 }
 
 /* ==========================================================================================

@@ -38,6 +38,9 @@ def lib():
         L.orc_ref_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p,
                                   C.c_size_t, C.c_void_p, f64p, C.c_size_t, u8p, C.c_void_p,
                                   C.c_void_p]
+        L.orc_ref_bench.restype = C.c_uint64
+        L.orc_ref_bench.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, u64p, C.c_size_t,
+                                    C.c_double, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.orc_threshold40.restype = C.c_uint64
         L.orc_threshold40.argtypes = [C.c_double, C.c_double]
         L.orc_lat_supported.argtypes = [C.c_int, C.c_int]
@@ -114,6 +117,15 @@ def ref_run(ea, eb, ej, nvars, seeds, betas, biases=None, initial=None, per_step
     lib().orc_ref_run(len(ea), ea, eb, ej, nvars, _ptr(b), seeds, R, _ptr(ini), betas, T, states,
                       _ptr(energies), _ptr(eps))
     return (energies, states, eps) if per_step else (energies, states)
+
+
+def ref_bench(ea, eb, ej, nvars, seeds, beta, timesteps, threads):
+    """Timed sweep loop of the reference-faithful engine; returns (seconds, attempts)."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    sec = C.c_double()
+    lib().orc_ref_bench(len(ea), ea, eb, ej, nvars, seeds, len(seeds), float(beta), timesteps,
+                        int(threads), C.byref(sec))
+    return sec.value, len(seeds) * nvars * timesteps
 
 
 def threshold40(beta, dE):
