@@ -53,7 +53,10 @@
 #define DOM_GEN_INIT 0x47454E49u  /* "GENI" */
 #define DOM_PT_SWAP 0x50545357u   /* "PTSW" */
 
-#define N_PLANES 8 /* bit-planes of the acceptance uniform drawn before the residual stage */
+#ifndef N_PLANES
+#define N_PLANES 7 /* bit-planes of the acceptance uniform drawn before the residual stage */
+#endif
+#define THR_BITS (N_PLANES + 32) /* fixed-point bits of an acceptance probability */
 
 /* ------------------------------------------------------------------------------------------
  * Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123).  Pinned by the Random123
@@ -302,13 +305,13 @@ uint64_t orc_ref_bench(size_t n_edges, const uint64_t *ea, const uint64_t *eb, c
  * Acceptance threshold, 40-bit fixed point: accept iff u40 < T, u40 uniform on [0, 2^40).
  * T = 2^40 (always) when dE <= 0 or exp(-beta dE) >= 1.
  * ======================================================================================== */
-uint64_t orc_threshold40(double beta, double dE)
+uint64_t orc_threshold_fixed(double beta, double dE)
 {
-    const uint64_t ONE = (uint64_t)1 << 40;
+    const uint64_t ONE = (uint64_t)1 << THR_BITS;
     if (dE <= 0.0) return ONE;
     double p = exp(-beta * dE);
     if (!(p < 1.0)) return ONE;
-    return (uint64_t)floor(p * 1099511627776.0);
+    return (uint64_t)floor(ldexp(p, THR_BITS));
 }
 
 /* ==========================================================================================
@@ -407,7 +410,7 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
                    const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)
 {
     lat_geom g = lat_make(W, H);
-    uint64_t T3 = orc_threshold40(beta, 4.0 * jabs), T4 = orc_threshold40(beta, 8.0 * jabs);
+    uint64_t T3 = orc_threshold_fixed(beta, 4.0 * jabs), T4 = orc_threshold_fixed(beta, 8.0 * jabs);
     size_t nquads = g.wpp / 4;
     for (uint32_t c = 0; c < 2; c++) {
         uint32_t *own = state + c * g.wpp;
@@ -431,11 +434,11 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
                     else {
                         uint64_t T = (k == 3) ? T3 : T4;
                         uint32_t hi = (uint32_t)(T >> 32), lo = (uint32_t)T;
-                        uint32_t u8 = 0;
+                        uint32_t upre = 0;
                         for (int p = 0; p < N_PLANES; p++)
-                            u8 = (u8 << 1) | ((planes[p][q] >> b) & 1u);
-                        if (u8 < hi) accept = 1;
-                        else if (u8 > hi) accept = 0;
+                            upre = (upre << 1) | ((planes[p][q] >> b) & 1u);
+                        if (upre < hi) accept = 1;
+                        else if (upre > hi) accept = 0;
                         else {
                             if ((n_undecided & 3) == 0)
                                 philox_seeded(seed, (uint32_t)Q, (uint32_t)t,

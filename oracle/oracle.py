@@ -41,8 +41,8 @@ def lib():
         L.orc_ref_bench.restype = C.c_uint64
         L.orc_ref_bench.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, u64p, C.c_size_t,
                                     C.c_double, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
-        L.orc_threshold40.restype = C.c_uint64
-        L.orc_threshold40.argtypes = [C.c_double, C.c_double]
+        L.orc_threshold_fixed.restype = C.c_uint64
+        L.orc_threshold_fixed.argtypes = [C.c_double, C.c_double]
         L.orc_lat_supported.argtypes = [C.c_int, C.c_int]
         L.orc_lat_state_words.restype = C.c_size_t
         L.orc_lat_state_words.argtypes = [C.c_int, C.c_int]
@@ -128,8 +128,8 @@ def ref_bench(ea, eb, ej, nvars, seeds, beta, timesteps, threads):
     return sec.value, len(seeds) * nvars * timesteps
 
 
-def threshold40(beta, dE):
-    return int(lib().orc_threshold40(beta, dE))
+def threshold_fixed(beta, dE):
+    return int(lib().orc_threshold_fixed(beta, dE))
 
 
 def det_exp(x):

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libisingmc.so")
+LIB_PATH = os.environ.get("ISINGMC_LIB_PATH") or os.path.join(_HERE, "lib", "libisingmc.so")  # override: A/B builds
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = range(5)
 KIND_GENERAL, KIND_LATTICE2D = 0, 1

@@ -145,18 +145,20 @@ static int use_device(int device)
 // ------------------------------------------------------------------------------------------------
 // small host helpers
 // ------------------------------------------------------------------------------------------------
-static uint64_t threshold40(double beta, double dE)
+// acceptance probability as a THR_BITS-bit fixed-point threshold: accept iff u < T, u uniform on
+// [0, 2^THR_BITS); T = 2^THR_BITS accepts always (dE <= 0, or beta < 0)
+static uint64_t threshold_fixed(double beta, double dE)
 {
-    const uint64_t ONE = uint64_t(1) << 40;
+    const uint64_t ONE = uint64_t(1) << THR_BITS;
     if (dE <= 0.0) return ONE;
     const double p = std::exp(-beta * dE);
     if (!(p < 1.0)) return ONE;
-    return uint64_t(std::floor(p * 1099511627776.0));
+    return uint64_t(std::floor(std::ldexp(p, THR_BITS)));
 }
 
 static LatThr lattice_thresholds(double beta, double jabs)
 {
-    return LatThr{threshold40(beta, 4.0 * jabs), threshold40(beta, 8.0 * jabs)};
+    return LatThr{threshold_fixed(beta, 4.0 * jabs), threshold_fixed(beta, 8.0 * jabs)};
 }
 
 template <typename F>

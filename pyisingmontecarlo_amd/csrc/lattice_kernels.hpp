@@ -25,10 +25,14 @@ struct LatGeom {
 };
 
 struct LatThr {
-    uint64_t T3, T4; // floor(exp(-beta dE) 2^40) for k = 3, 4; 2^40 = always accept
+    uint64_t T3, T4; // floor(exp(-beta dE) 2^THR_BITS) for k = 3, 4; 2^THR_BITS = always accept
 };
 
-constexpr int N_PLANES = 8;
+#ifndef ISINGMC_N_PLANES
+#define ISINGMC_N_PLANES 7
+#endif
+constexpr int N_PLANES = ISINGMC_N_PLANES;
+constexpr int THR_BITS = N_PLANES + 32; // acceptance probabilities are fixed-point with this many bits
 
 __device__ __forceinline__ uint32_t sel4(uint4 v, uint32_t i)
 {
@@ -142,8 +146,10 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
 
     // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
     uint32_t eq4[4], lt[4], und[4], le2[4];
-    const bool all3 = (thr.T3 >> 40) != 0, all4 = (thr.T4 >> 40) != 0;
-    const uint32_t hi3 = uint32_t(thr.T3 >> 32) & 0xFFu, hi4 = uint32_t(thr.T4 >> 32) & 0xFFu;
+    // thresholds have THR_BITS = N_PLANES + 32 bits: the top N_PLANES are compared bit-sliced, the
+    // low 32 against one residual Philox word
+    const bool all3 = (thr.T3 >> THR_BITS) != 0, all4 = (thr.T4 >> THR_BITS) != 0;
+    const uint32_t hi3 = uint32_t(thr.T3 >> 32) & ((1u << N_PLANES) - 1), hi4 = uint32_t(thr.T4 >> 32) & ((1u << N_PLANES) - 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t a0, a1, a2, a3;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
 #pragma unroll
     for (int p = 0; p < N_PLANES; p++) {
         const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, p), DOM_LAT_SWEEP), key);
-        const uint32_t m3 = 0u - ((hi3 >> (7 - p)) & 1u), m4 = 0u - ((hi4 >> (7 - p)) & 1u);
+        const uint32_t m3 = 0u - ((hi3 >> (N_PLANES - 1 - p)) & 1u), m4 = 0u - ((hi4 >> (N_PLANES - 1 - p)) & 1u);
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -179,14 +185,16 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     if (und[0] | und[1] | und[2] | und[3]) {
         const uint32_t lo3 = uint32_t(thr.T3), lo4 = uint32_t(thr.T4);
         uint32_t nres = 0;
-        uint4 rnd = make_uint4(0, 0, 0, 0);
+        // the first residual call is hoisted: inside the divergent per-word loops below it would be
+        // issued once per loop (up to 4x per wave) instead of once
+        uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, N_PLANES), DOM_LAT_SWEEP), key);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t m = und[q];
             while (m) {
                 const uint32_t b = __ffs(m) - 1;
                 m &= m - 1;
-                if ((nres & 3u) == 0)
+                if (nres != 0 && (nres & 3u) == 0) // 5th, 9th, ... tie of this quad: rare
                     rnd = philox4x32_10(
                         make_uint4(c0, c1, ctr2(t, colour, N_PLANES + (nres >> 2)), DOM_LAT_SWEEP), key);
                 const uint32_t lo = ((eq4[q] >> b) & 1u) ? lo4 : lo3;
