@@ -90,6 +90,16 @@ int isingmc_host_recognise_lattice2d(const uint64_t *edge_a, const uint64_t *edg
 int isingmc_host_colour_graph(const uint64_t *edge_a, const uint64_t *edge_b, size_t n_edges,
                               size_t nvars, uint32_t *colours_out, uint32_t *n_colours_out);
 
+/* One exchange round of the classical parallel-tempering ladder -- the classical counterpart of
+ * TemperingContainer::parallel_tempering_step driven from tempering.rs:191-194 (quantum in the
+ * reference).  Rung i has inverse temperature betas[i] and currently holds replica slot perm[i];
+ * slot_energy[s] is that slot's energy (all-gathered across ranks by the caller).  Pairs (i, i+1)
+ * with i of the round's parity are swapped with probability min(1, exp((b_i-b_j)(E_i-E_j))) using
+ * a Philox stream keyed by (seed, round, i): every rank computes the same decisions from the same
+ * inputs.  perm is updated in place; *swaps_out receives the number of accepted swaps. */
+int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
+                               const double *slot_energy, uint32_t *perm, uint64_t *swaps_out);
+
 /* ---- graph: replaces the adjacency half of GraphState::new (lattice.rs:199, classicising.rs:73)
  * edges as three parallel arrays (the Vec<((usize,usize),f64)> of lattice.rs:47); biases NULL
  * (all zero) or nvars doubles (lattice.rs:186-189).  device = HIP ordinal. */

@@ -10,4 +10,6 @@ _ext = _load()
 Lattice = _ext.Lattice
 ClassicIsing = _ext.ClassicIsing
 
-__all__ = ["Lattice", "ClassicIsing"]
+from pyisingmontecarlo_amd.tempering import ClassicalTempering  # noqa: E402
+
+__all__ = ["Lattice", "ClassicIsing", "ClassicalTempering"]

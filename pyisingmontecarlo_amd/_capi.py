@@ -30,6 +30,8 @@ _PROTOTYPES = {
                                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                    C.POINTER(C.c_int)]),
     "isingmc_host_colour_graph": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint32)]),
+    "isingmc_host_pt_swap_round": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp, _vp,
+                                             C.POINTER(C.c_uint64)]),
     "isingmc_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_uint, C.POINTER(_vp)]),
     "isingmc_graph_info": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
     "isingmc_graph_destroy": (None, [_vp]),
@@ -124,6 +126,16 @@ def colour_graph(ea, eb, nvars):
     nc = C.c_uint32()
     _check(lib().isingmc_host_colour_graph(_p(ea), _p(eb), len(ea), nvars, _p(colours), C.byref(nc)))
     return nc.value, colours
+
+
+def pt_swap_round(seed, rnd, betas, slot_energy, perm):
+    """One exchange round of the beta ladder; perm (uint32, rung -> slot) is updated in place."""
+    betas, slot_energy = _arr(betas, np.float64), _arr(slot_energy, np.float64)
+    assert perm.dtype == np.uint32 and perm.flags.c_contiguous
+    swaps = C.c_uint64()
+    _check(lib().isingmc_host_pt_swap_round(C.c_uint64(int(seed)), C.c_uint64(int(rnd)), len(betas), _p(betas),
+                                            _p(slot_energy), _p(perm), C.byref(swaps)))
+    return swaps.value
 
 
 class Graph:

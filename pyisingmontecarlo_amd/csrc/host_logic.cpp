@@ -192,3 +192,65 @@ Colouring greedy_colouring(const Adjacency &A, size_t nvars)
 }
 
 } // namespace isingmc
+
+// ---- parallel-tempering swap step (classical ladder; scheduling shaped after tempering.rs:172-212)
+namespace isingmc {
+
+static void philox4x32_10_host(const uint32_t ctr[4], uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0, n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c1 = uint32_t(p1);
+        c3 = uint32_t(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// same arithmetic as the device det_exp (general_kernels.hpp): f64 + fma only
+static double det_exp_host(double x)
+{
+    if (x >= 0.0) return 1.0;
+    if (x < -40.0) return 0.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double kf = std::floor(std::fma(x, LOG2E, 0.5));
+    double r = std::fma(-kf, LN2_HI, x);
+    r = std::fma(-kf, LN2_LO, r);
+    const double coef[13] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                             1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0,
+                             1.0 / 6.0, 0.5, 1.0, 1.0};
+    double p = 1.0 / 6227020800.0;
+    for (double c : coef) p = std::fma(p, r, c);
+    return std::ldexp(p, int(kf));
+}
+
+uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
+                       const double *slot_energy, uint32_t *perm)
+{
+    uint64_t swaps = 0;
+    for (size_t i = round & 1; i + 1 < n_rungs; i += 2) { // even rounds pair (0,1),(2,3).., odd (1,2),..
+        const double d = (betas[i] - betas[i + 1]) * (slot_energy[perm[i]] - slot_energy[perm[i + 1]]);
+        bool accept = d >= 0.0;
+        if (!accept) {
+            const uint32_t ctr[4] = {uint32_t(i), uint32_t(round), uint32_t(round >> 32), 0x50545357u /* "PTSW" */};
+            uint32_t r[4];
+            philox4x32_10_host(ctr, uint32_t(seed), uint32_t(seed >> 32), r);
+            const uint64_t x = (uint64_t(r[1]) << 32) | r[0];
+            const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
+            accept = u < det_exp_host(d);
+        }
+        if (accept) {
+            std::swap(perm[i], perm[i + 1]);
+            swaps++;
+        }
+    }
+    return swaps;
+}
+
+} // namespace isingmc

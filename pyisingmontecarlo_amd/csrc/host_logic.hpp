@@ -55,4 +55,11 @@ struct Colouring {
 
 Colouring greedy_colouring(const Adjacency &A, size_t nvars);
 
+// One parallel-tempering exchange round on the beta ladder.  Rung i (beta_i) holds
+// replica slot perm[i]; round parity picks the pairs (i, i+1); swap iff
+// u < exp((beta_i - beta_j)(E_i - E_j)), u from Philox keyed by (seed, round, i).  Swaps exchange the
+// perm entries (temperatures move, configurations stay).  Returns the number of accepted swaps.
+uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
+                       const double *slot_energy, uint32_t *perm);
+
 } // namespace isingmc

@@ -295,6 +295,17 @@ extern "C" int isingmc_host_colour_graph(const uint64_t *ea, const uint64_t *eb,
     return ISINGMC_OK;
 }
 
+extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
+                                          const double *slot_energy, uint32_t *perm, uint64_t *swaps_out)
+{
+    if (n_rungs && (!betas || !slot_energy || !perm)) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < n_rungs; i++)
+        if (perm[i] >= n_rungs) return fail(ISINGMC_ERR_INVALID, "perm is not a permutation of the rungs");
+    const uint64_t swaps = pt_swap_round(seed, round, n_rungs, betas, slot_energy, perm);
+    if (swaps_out) *swaps_out = swaps;
+    return ISINGMC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------

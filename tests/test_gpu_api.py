@@ -1,0 +1,271 @@
+"""GPU tests of the drop-in Python API (py_monte_carlo) and of the full-size properties.
+
+Small cases are checked against the oracle bit for bit; BASELINE.json's full sizes through
+size-independent properties (energy recomputation from the returned states, exact limits,
+shard invariance) and against exact physics within Monte-Carlo error.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _edges(ea, eb, ej):
+    return [((int(a), int(b)), float(j)) for a, b, j in zip(ea, eb, ej)]
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import py_monte_carlo
+    return py_monte_carlo
+
+
+def test_run_monte_carlo_c1_shape_and_oracle(mod, oracle, exact):
+    """BASELINE config c1: 16x16, beta=0.3, num_experiments=4 (general path on the GPU)."""
+    ea, eb, ej = exact.square_lattice_edges(16, 16, -1.0)
+    lat = mod.Lattice(_edges(ea, eb, ej), seed_gen=1234)
+    assert lat.engine_info()["kind"] == "general"
+    energies, states = lat.run_monte_carlo(0.3, 1000, 4)
+    assert energies.shape == (4,) and energies.dtype == np.float64
+    assert states.shape == (4, 256) and states.dtype == np.bool_ and states.flags.c_contiguous
+    for r, s in enumerate(lat.make_seeds(4)):
+        e_ref, s_ref = oracle.gen_run(ea, eb, ej, 256, s, [0.3] * 1000)
+        assert np.array_equal(states[r], s_ref.astype(bool)) and energies[r] == e_ref
+    e2, s2 = lat.run_monte_carlo(0.3, 1000, 4)       # seed_gen set: reruns reuse the seeds (lattice.rs:76-80)
+    assert np.array_equal(e2, energies) and np.array_equal(s2, states)
+
+
+def test_readme_example_runs(mod, oracle):
+    lat = mod.Lattice([((0, 1), 1.0), ((1, 2), -1.0)])
+    e, s = lat.run_monte_carlo(1.0, 100, 8)
+    ea, eb, ej = oracle.split_edges([((0, 1), 1.0), ((1, 2), -1.0)])
+    for r in range(8):
+        assert e[r] == oracle.energy(ea, eb, ej, 3, s[r])
+    assert set(np.unique(e)) <= {-2.0, 0.0, 2.0}
+
+
+def test_sampling_semantics(mod, oracle, exact):
+    """lattice.rs:244-250, 271-287: S = T // freq samples, each after `freq` more steps, after thermalisation."""
+    W, H = 64, 8
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=5)
+    assert lat.engine_info()["kind"] == "lattice2d"
+    energies, states = lat.run_monte_carlo_sampling(0.5, 10, 3, None, 4, 3)   # therm=4, freq=3 -> S=3
+    assert energies.shape == (3, 3) and states.shape == (3, 3, W * H) and states.dtype == np.bool_
+    olat = oracle.Lat(W, H)
+    for r, seed in enumerate(lat.make_seeds(3)):
+        st = olat.init(seed)
+        t = 0
+        for _ in range(4):
+            olat.sweep(st, seed, t, 0.5); t += 1
+        for k in range(3):
+            for _ in range(3):
+                olat.sweep(st, seed, t, 0.5); t += 1
+            assert np.array_equal(states[r, k], olat.unpack(st).astype(bool))
+            assert energies[r, k] == olat.energy_mag(st)[0]
+    e1, s1 = lat.run_monte_carlo_sampling(0.5, 7, 2)                        # defaults: therm 0, freq 1
+    assert e1.shape == (2, 7) and s1.shape == (2, 7, W * H)
+    with pytest.raises(ValueError):
+        lat.run_monte_carlo_sampling(0.5, 7, 2, sampling_freq=0)
+
+
+def test_annealing_and_energies(mod, oracle, exact):
+    W, H = 128, 8
+    ea, eb, ej = exact.square_lattice_edges(W, H, 1.0, np.random.default_rng(2024))
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=9)
+    T = 12
+    stops = [(0, 0.1), (6, 1.0), (12, 3.0)]
+    e_all, s_fin = lat.run_monte_carlo_annealing_and_get_energies(stops, T, 2)
+    e_fin, s_fin2 = lat.run_monte_carlo_annealing(stops, T, 2)
+    assert e_all.shape == (2, T) and s_fin.shape == (2, W * H)
+    assert np.array_equal(s_fin, s_fin2) and np.array_equal(e_all[:, -1], e_fin)
+    from pyisingmontecarlo_amd import _capi
+    betas = _capi.expand_schedule(stops, T)
+    olat = oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8))
+    for r, seed in enumerate(lat.make_seeds(2)):
+        st = olat.init(seed)
+        for t in range(T):
+            olat.sweep(st, seed, t, betas[t])
+            assert e_all[r, t] == olat.energy_mag(st)[0]
+        assert np.array_equal(s_fin[r], olat.unpack(st).astype(bool))
+    e_def, _ = lat.run_monte_carlo_annealing([], T, 2)                      # default schedule beta = 1 (lattice.rs:321-324)
+    e_one, _ = lat.run_monte_carlo(1.0, T, 2)
+    assert np.array_equal(e_def, e_one)
+
+
+def test_annealing_compat_mode_is_constant_beta(mod, exact, monkeypatch):
+    ea, eb, ej = exact.square_lattice_edges(64, 8, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=3)
+    monkeypatch.setenv("ISINGMC_COMPAT_ANNEAL_BUG", "1")
+    e_bug, s_bug = lat.run_monte_carlo_annealing([(0, 0.1), (10, 0.7)], 10, 2)
+    monkeypatch.delenv("ISINGMC_COMPAT_ANNEAL_BUG")
+    e_const, s_const = lat.run_monte_carlo(0.7, 10, 2)
+    assert np.array_equal(s_bug, s_const) and np.array_equal(e_bug, e_const)
+
+
+def test_initial_state_and_bias_paths(mod, oracle, exact):
+    ea, eb, ej = exact.square_lattice_edges(64, 8, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=2)
+    ini = (np.arange(512) % 2 == 0)
+    lat.set_initial_state(ini.tolist())
+    e, s = lat.run_monte_carlo(0.4, 0, 2)                                   # zero timesteps: the initial state comes back
+    assert np.array_equal(s[0], ini) and np.array_equal(s[1], ini)
+    assert e[0] == oracle.energy(ea, eb, ej, 512, ini.astype(np.uint8))
+    lat.set_initial_state([])
+    lat.set_global_bias(0.25)                                               # a field -> general path
+    assert lat.engine_info()["kind"] == "general"
+    e, s = lat.run_monte_carlo(0.4, 20, 2)
+    for r, seed in enumerate(lat.make_seeds(2)):
+        e_ref, s_ref = oracle.gen_run(ea, eb, ej, 512, seed, [0.4] * 20, biases=np.full(512, 0.25))
+        assert np.array_equal(s[r], s_ref.astype(bool)) and abs(e[r] - e_ref) < 1e-9
+    lat.set_individual_bias(7, -3.0)
+    e, s = lat.run_monte_carlo(0.4, 5, 1)
+    b = np.full(512, 0.25); b[7] = -3.0
+    e_ref, s_ref = oracle.gen_run(ea, eb, ej, 512, lat.make_seeds(1)[0], [0.4] * 5, biases=b)
+    assert np.array_equal(s[0], s_ref.astype(bool))
+
+
+def test_replica_range_is_shard_invariant(mod, exact):
+    """K8: keyed by global experiment index, any sharding of the experiments gives the same arrays."""
+    ea, eb, ej = exact.square_lattice_edges(256, 16, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=1)
+    e, s = lat.run_monte_carlo(0.4407, 9, 8)
+    parts = [lat.run_monte_carlo(0.4407, 9, 8, replica_range=r) for r in [(0, 3), (3, 4), (4, 8)]]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), e)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), s)
+    with pytest.raises(ValueError):
+        lat.run_monte_carlo(0.4407, 1, 8, replica_range=(5, 9))
+
+
+def test_classic_ising_persistent(mod, oracle, exact):
+    W, H = 64, 8
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    ci = mod.ClassicIsing(_edges(ea, eb, ej), None, 2, 42)
+    assert ci.get_num_graphs() == 2
+    ci.add_graph([True] * (W * H))
+    assert ci.run_monte_carlo(0.5, 4) is None                               # classicising.rs:88-110 returns nothing
+    ci.run_monte_carlo(0.5, 3, nspinupdates=2 * W * H)                      # 2 sweeps per timestep
+    seeds = oracle.make_seeds(42, 3)                                        # the container rng's draws (classicising.rs:67)
+    olat = oracle.Lat(W, H)
+    states, energies = ci.get_states(), ci.get_energies()
+    for r in range(3):
+        st = olat.init(seeds[r]) if r < 2 else olat.pack(np.ones(W * H, dtype=np.uint8))
+        for t in range(10):
+            olat.sweep(st, seeds[r], t, 0.5)
+        assert np.array_equal(states[r], olat.unpack(st).astype(bool)) and energies[r] == olat.energy_mag(st)[0]
+    e, s = ci.run_monte_carlo_sampling(0.5, 6, None, None, None, None, 2, 2)
+    assert e.shape == (3, 3) and s.shape == (3, 3, W * H)
+    with pytest.raises(ValueError, match="multiple"):
+        ci.run_monte_carlo(0.5, 1, nspinupdates=7)
+    with pytest.raises(ValueError):
+        mod.ClassicIsing([])
+    field = mod.ClassicIsing(_edges(ea, eb, ej), 0.5, 1, 1)                 # longitudinal field -> general path
+    field.run_monte_carlo(0.3, 5)
+    e_ref, s_ref = oracle.gen_run(ea, eb, ej, W * H, oracle.make_seeds(1, 1)[0], [0.3] * 5, biases=np.full(W * H, 0.5))
+    assert np.array_equal(field.get_states()[0], s_ref.astype(bool))
+
+
+def _blocked(x, n=16):
+    m = np.array([b.mean() for b in np.array_split(np.asarray(x, dtype=np.float64), n)])
+    return m.mean(), m.std(ddof=1) / math.sqrt(n)
+
+
+def test_equilibrium_energy_vs_kaufman(capi, exact):
+    """K3 on the GPU: <E> against the exact finite-torus value, error from independent replicas.
+    256x256 away from T_c; at beta_c a 64x64 torus (critical slowing down: tau ~ L^2.17 sweeps)."""
+    for L, beta, therm, steps, R in ((256, 0.3, 300, 1500, 32), (256, 0.6, 500, 1500, 32),
+                                     (64, 0.4407, 20000, 40000, 64)):
+        ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+        g = capi.Graph(ea, eb, ej)
+        st = capi.States(g, capi.make_seeds(17, R), initial_state=np.ones(L * L, dtype=np.uint8))
+        st.do_time_steps(therm, beta)
+        per_replica = st.do_time_steps(steps, beta, per_step_energies=True).mean(axis=1)
+        mean, err = per_replica.mean(), per_replica.std(ddof=1) / math.sqrt(R)
+        ref = exact.kaufman_energy(L, L, beta)
+        assert abs(mean - ref) < 4.5 * err, (L, beta, mean, ref, err)
+        assert err < 3e-3 * abs(ref)
+
+
+def test_observables_vs_reference_faithful_cpu_engine(capi, oracle, exact):
+    """K6: <E> and <|M|> of the checkerboard kernel against the random-site sequential CPU engine
+    (oracle engine A, the restatement of the reference's algorithm): two-sample z-tests."""
+    W = H = 64
+    beta = 0.42
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, capi.make_seeds(3, 64))
+    st.do_time_steps(3000, beta)
+    ms, es = [], []
+    for _ in range(80):
+        st.do_time_steps(50, beta)
+        ms.append(np.abs(st.magnetisations()))
+        es.append(st.energies())
+    gm, ge = np.mean(ms, axis=0), np.mean(es, axis=0)                       # one time average per replica
+    _, _, eps = oracle.ref_run(ea, eb, ej, W * H, oracle.make_seeds(8, 16), [beta] * 4000, per_step=True)
+    ce = eps[:, 2000:].mean(axis=1)
+    z = (ge.mean() - ce.mean()) / math.sqrt(ge.var(ddof=1) / len(ge) + ce.var(ddof=1) / len(ce))
+    assert abs(z) < 4.5, ("energy", z)
+    _, finals = oracle.ref_run(ea, eb, ej, W * H, oracle.make_seeds(9, 64), [beta] * 3000)
+    cpu_absm = np.abs(2.0 * finals.sum(axis=1) - W * H)
+    gpu_absm = np.abs(st.magnetisations()).astype(np.float64)              # end-of-chain samples on both sides
+    z = (gpu_absm.mean() - cpu_absm.mean()) / math.sqrt(gpu_absm.var(ddof=1) / 64 + cpu_absm.var(ddof=1) / 64)
+    assert abs(z) < 4.5, ("|M|", z)
+    assert abs(gm.mean() - cpu_absm.mean()) < 0.15 * W * H
+
+
+def test_full_size_properties_4096(capi, exact):
+    """BASELINE c2's lattice (4096^2), few replicas: properties that do not need the oracle."""
+    L = 4096
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    assert g.kind == capi.KIND_LATTICE2D
+    seeds = capi.make_seeds(1, 3)
+    st = capi.States(g, seeds)
+    before = st.states()
+    m0 = st.magnetisations()
+    assert np.all(np.abs(m0) < 6 * L)                                       # random start: |M| ~ sqrt(N)
+    st.do_time_steps(1, 0.0)                                                # beta = 0: every attempt accepted (K4)
+    assert np.array_equal(st.states(), ~before)
+    assert np.array_equal(st.magnetisations(), -m0)
+    st.do_time_steps(30, 0.4407)
+    spins = st.states()
+    e = st.energies()
+    s2 = spins.reshape(3, L, L).astype(np.int8) * 2 - 1                     # K1: recompute sum J s s on the host
+    e_host = -(s2 * np.roll(s2, -1, axis=2)).sum(axis=(1, 2), dtype=np.int64) - (s2 * np.roll(s2, -1, axis=1)).sum(axis=(1, 2), dtype=np.int64)
+    assert np.array_equal(e, e_host.astype(np.float64))
+    assert np.array_equal(st.magnetisations(), s2.sum(axis=(1, 2), dtype=np.int64))
+    assert np.all(e / L ** 2 < -1.2)                                         # relaxing towards -sqrt(2)
+    cold = capi.States(g, seeds[:1], initial_state=np.ones(L * L, dtype=np.uint8))
+    cold.do_time_steps(2, 20.0)                                             # ordered and cold: nothing moves (K4)
+    assert cold.energies()[0] == -2.0 * L * L and cold.magnetisations()[0] == L * L
+    # shard invariance at full size: replica 2 alone == replica 2 of the batch
+    solo = capi.States(g, seeds[2:3])
+    solo.do_time_steps(1, 0.0)
+    solo.do_time_steps(30, 0.4407)
+    assert np.array_equal(solo.packed()[0], st.packed()[2])
+
+
+def test_tempering_matches_oracle_engine(capi, exact):
+    """The classical ladder on the GPU against the same host logic driven by the CPU oracle engine."""
+    from helpers import OracleLatEngine
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    W, H = 64, 8
+    edges = exact.square_lattice_edges(W, H, -1.0)
+    runs = []
+    for factory in (None, lambda: OracleLatEngine(W, H)):
+        pt = ClassicalTempering(edges, seed=5, engine_factory=factory)
+        for b in np.linspace(0.38, 0.5, 7):
+            pt.add_graph(b)
+        pt.timesteps(5)
+        states, energies = pt.timesteps_sample(24, replica_swap_freq=3, sampling_freq=6)
+        runs.append((states, energies, pt.get_permutation(), pt.get_total_swaps()))
+    assert runs[0][3] == runs[1][3] > 0                                     # K7: swaps happen, identically
+    assert np.array_equal(runs[0][2], runs[1][2])
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert runs[0][0].shape == (7, 4, W * H)
