@@ -29,7 +29,7 @@
  *
  *  B. orc_lat_*   serial, per-spin restatement of the build's own 2-colour checkerboard
  *                 algorithm on a periodic W x H square lattice with uniform |J| (DESIGN.md
- *                 "Algorithm specification", S3).  Same Philox counters, same 40-bit
+ *                 "Algorithm specification", S3).  Same Philox counters, same fixed-point
  *                 acceptance thresholds => the HIP kernels must reproduce its spin
  *                 configurations BIT FOR BIT.  Written spin-by-spin (no bit-slicing) on purpose,
  *                 so that it checks the kernel's bit-sliced logic independently.
@@ -302,8 +302,8 @@ uint64_t orc_ref_bench(size_t n_edges, const uint64_t *ea, const uint64_t *eb, c
 }
 
 /* ==========================================================================================
- * Acceptance threshold, 40-bit fixed point: accept iff u40 < T, u40 uniform on [0, 2^40).
- * T = 2^40 (always) when dE <= 0 or exp(-beta dE) >= 1.
+ * Acceptance threshold, THR_BITS-bit fixed point: accept iff u < T, u uniform on [0, 2^THR_BITS).
+ * T = 2^THR_BITS (always) when dE <= 0 or exp(-beta dE) >= 1.
  * ======================================================================================== */
 uint64_t orc_threshold_fixed(double beta, double dE)
 {
@@ -402,9 +402,9 @@ static int lat_satisfied(const lat_geom *g, const uint32_t *state, const uint8_t
 
 /*
  * S3: one timestep t = colour 0 pass then colour 1 pass.  Flipping a spin with k satisfied
- * bonds costs dE = 2|J|(2k-4): k<=2 always flips, k=3 / k=4 flip iff u40 < T3 / T4 with
- * u40 = (8-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only when
- * the prefix equals the threshold's top 8 bits).
+ * bonds costs dE = 2|J|(2k-4): k<=2 always flips, k=3 / k=4 flip iff u < T3 / T4 with
+ * u = (N_PLANES-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only
+ * when the prefix equals the threshold's top N_PLANES bits: a "tie").
  */
 void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
                    const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)

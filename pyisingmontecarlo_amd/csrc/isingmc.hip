@@ -637,7 +637,8 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
     const isingmc_graph *g = s->g;
     for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
         const size_t n = std::min(MAX_GRID_Y, s->R - r0);
-        hipLaunchKernelGGL((lat_measure_kernel<VEC, PMJ>), lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
+        const uint32_t blocks = (g->geom.nquads + 256 * MEASURE_QUADS_PER_THREAD - 1) / (256 * MEASURE_QUADS_PER_THREAD);
+        hipLaunchKernelGGL((lat_measure_kernel<VEC, PMJ>), dim3(blocks, unsigned(n)), dim3(256), 0, s->stream,
                            s->d_state + r0 * g->state_words, g->geom, g->d_jneg, g->jneg_uniform,
                            out + r0 * out_stride, out_stride);
     }

@@ -8,10 +8,10 @@
 //
 // Acceptance: a spin with k satisfied bonds flips always for k <= 2 and with
 // probability exp(-beta 2|J|(2k-4)) for k = 3, 4.  All 128 decisions of a quad are taken
-// bit-sliced: Philox call p (p = 0..7) yields bit-plane p of the spins' 8-bit uniform prefixes,
-// compared MSB-first against the top 8 bits of the 40-bit threshold of each spin's class.  The few
-// spins whose prefix ties the threshold (1/128 of them) are resolved with one 32-bit Philox word
-// each.  Everything is integer: the CPU oracle reproduces the configurations bit for bit.
+// bit-sliced: Philox call p (p = 0..N_PLANES-1) yields bit-plane p of the spins' uniform prefixes,
+// compared MSB-first against the top N_PLANES bits of the fixed-point threshold of each spin's class.
+// The few spins whose prefix ties the threshold (2^-N_PLANES of them) are resolved with one 32-bit
+// Philox word each.  Everything is integer: the CPU oracle reproduces the configurations bit for bit.
 #pragma once
 #include "philox.hpp"
 
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
         eq4[q] = c01 & c23;
         const uint32_t eq3 = (c01 & s23) | (c23 & s01);
         le2[q] = ~(eq3 | eq4[q]);
-        lt[q] = (all3 ? eq3 : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^40: accepted outright
+        lt[q] = (all3 ? eq3 : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^THR_BITS: accepted outright
         und[q] = (eq3 | eq4[q]) & ~lt[q];
     }
 
-    // 8 bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
+    // N_PLANES bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
     const uint32_t c0 = Q, c1 = uint32_t(t);
 #pragma unroll
     for (int p = 0; p < N_PLANES; p++) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
         }
     }
 
-    // residual stage: spins whose prefix equals the threshold's top byte draw 32 more bits
+    // residual stage: spins whose prefix equals the threshold's top bits (ties) draw 32 more bits
     uint32_t acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = le2[q] | lt[q];
@@ -229,16 +229,23 @@ __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ st
 // Full recomputation of the satisfied-bond count and the up-spin count of every replica
 // (get_energy, lattice.rs:208): every bond joins a colour-0 site to a colour-1 site, so the four
 // bonds of the colour-0 sites cover each bond once.  out[2r] += satisfied, out[2r+1] += up spins.
+constexpr uint32_t MEASURE_QUADS_PER_THREAD = 16;
+
 template <bool VEC, bool PMJ>
 __global__ __launch_bounds__(256) void lat_measure_kernel(
     const uint32_t *__restrict__ state, const LatGeom g, const uint32_t *__restrict__ jneg,
     const uint32_t jneg_uniform, unsigned long long *__restrict__ out, const size_t out_stride)
 {
+    // each block walks MEASURE_QUADS_PER_THREAD x 256 quads (coalesced, stride 256), reduces in the
+    // wavefront with __shfl_xor and across its 4 waves through LDS: ONE atomic pair per block
+    // (one pair per wave on two addresses per replica serialised the whole kernel)
+    __shared__ uint32_t red[2][4];
     const uint32_t r = blockIdx.y;
-    const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
     uint32_t sat = 0, up = 0;
-    if (Q < g.nquads) {
-        const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
+    const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
+    for (uint32_t i = 0; i < MEASURE_QUADS_PER_THREAD; i++) {
+        const uint32_t Q = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
+        if (Q >= g.nquads) break;
         uint32_t own[4], widx[4];
         QuadNbr n;
         load_quad<VEC>(p0, p0 + g.wpp, g, 0, Q, own, n, widx);
@@ -250,15 +257,19 @@ __global__ __launch_bounds__(256) void lat_measure_kernel(
             up += __popc(own[q]) + __popc(n.ce[q]);
         }
     }
-    // wavefront reduction (64 lanes), then one atomic per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sat += __shfl_xor(sat, off);
         up += __shfl_xor(up, off);
     }
-    if ((threadIdx.x & 63) == 0 && (sat | up)) {
-        atomicAdd(out + size_t(r) * out_stride, (unsigned long long)sat);
-        atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)up);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sat;
+        red[1][threadIdx.x >> 6] = up;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out + size_t(r) * out_stride, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
 }
 

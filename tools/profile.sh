@@ -8,10 +8,11 @@ set -euo pipefail
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-ARGS=${*:---steps 50 --warmup 5 --no-cpu-baseline}
+ARGS=${*:---steps 50 --warmup 5 --no-cpu-baseline}   # PMC passes: counters are per launch
+TRACE_ARGS=${TRACE_ARGS:---no-cpu-baseline}          # trace pass: the default bench (1000 steps + 100 warm-up)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $TRACE_ARGS > "$OUT/trace.log" 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 echo "fetch done"
