@@ -65,37 +65,59 @@ __device__ __forceinline__ double local_field(const GenGraphDev &G, const uint32
     return field;
 }
 
-// one colour class of one timestep, all replicas (blockIdx.y)
-template <typename WT>
+// One colour class of one timestep.  A thread owns one site for RB replicas (blockIdx.y = replica
+// group): the CSR row (index + coupling per directed edge, the dominant stream) is read once per RB
+// replicas instead of once per replica; only the bit gathers stay per replica.  The per-site
+// arithmetic is replica-local and unchanged, so the result does not depend on RB.
+template <typename WT, int RB>
 __global__ __launch_bounds__(256) void gen_sweep_kernel(
     uint32_t *__restrict__ state, const GenGraphDev G, const uint32_t class_begin,
     const uint32_t class_end, const uint64_t t, const uint2 *__restrict__ keys,
-    const double beta_uniform, const double *__restrict__ beta_replica)
+    const double beta_uniform, const double *__restrict__ beta_replica, const uint32_t n_replicas)
 {
-    const uint32_t r = blockIdx.y;
+    const uint32_t r0 = blockIdx.y * RB;
     const uint32_t p = class_begin + blockIdx.x * 256 + threadIdx.x;
     if (p >= class_end) return; // class sizes are multiples of 64: whole waves leave together
-    uint32_t *st = state + size_t(r) * G.n_words;
     const uint32_t site = G.site[p];
-    bool flip = false;
+    const WT *w = static_cast<const WT *>(G.w);
+    double field[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) field[k] = 0.0;
     if (site != PAD_SITE) {
-        const double beta = beta_replica ? beta_replica[r] : beta_uniform;
-        const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
-        const double field = local_field<WT>(G, st, p);
-        const double dE = 2.0 * si * ((G.bias ? G.bias[p] : 0.0) - field);
-        flip = dE <= 0.0;
-        if (!flip) {
-            const uint4 rnd =
-                philox4x32_10(make_uint4(site >> 1, uint32_t(t), ctr2(t, 0, 0), DOM_GEN_SWEEP), keys[r]);
-            const uint64_t x = (site & 1u) ? (uint64_t(rnd.w) << 32 | rnd.z) : (uint64_t(rnd.y) << 32 | rnd.x);
-            const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
-            flip = u < det_exp(-beta * dE);
+        for (uint32_t e = G.rowptr[p], end = G.rowptr[p + 1]; e < end; e++) {
+            const uint32_t q = G.nbr[e];
+            const double j = double(w[e]);
+            const uint32_t *word = state + size_t(r0) * G.n_words + (q >> 5);
+#pragma unroll
+            for (int k = 0; k < RB; k++)
+                if (r0 + k < n_replicas) field[k] += ((word[size_t(k) * G.n_words] >> (q & 31)) & 1u) ? j : -j;
         }
     }
-    const unsigned long long mask = __ballot(flip);
-    if ((threadIdx.x & 63) == 0 && mask) {
-        st[p >> 5] ^= uint32_t(mask);
-        st[(p >> 5) + 1] ^= uint32_t(mask >> 32);
+    const double bias = (site != PAD_SITE && G.bias) ? G.bias[p] : 0.0;
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const uint32_t r = r0 + k;
+        if (r >= n_replicas) break; // wave-uniform
+        uint32_t *st = state + size_t(r) * G.n_words;
+        bool flip = false;
+        if (site != PAD_SITE) {
+            const double beta = beta_replica ? beta_replica[r] : beta_uniform;
+            const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
+            const double dE = 2.0 * si * (bias - field[k]);
+            flip = dE <= 0.0;
+            if (!flip) {
+                const uint4 rnd =
+                    philox4x32_10(make_uint4(site >> 1, uint32_t(t), ctr2(t, 0, 0), DOM_GEN_SWEEP), keys[r]);
+                const uint64_t x = (site & 1u) ? (uint64_t(rnd.w) << 32 | rnd.z) : (uint64_t(rnd.y) << 32 | rnd.x);
+                const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
+                flip = u < det_exp(-beta * dE);
+            }
+        }
+        const unsigned long long mask = __ballot(flip);
+        if ((threadIdx.x & 63) == 0 && mask) {
+            st[p >> 5] ^= uint32_t(mask);
+            st[(p >> 5) + 1] ^= uint32_t(mask >> 32);
+        }
     }
 }
 

@@ -651,22 +651,36 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
         else { if (pmj__) fn<false, true>(__VA_ARGS__); else fn<false, false>(__VA_ARGS__); }       \
     } while (0)
 
+#ifndef ISINGMC_GEN_RB
+#define ISINGMC_GEN_RB 8
+#endif
+constexpr int GEN_RB = ISINGMC_GEN_RB; // replicas per thread on the general path (amortises the CSR stream)
+
+template <typename WT, int RB>
+static void launch_gen_class(isingmc_states *s, uint32_t b, uint32_t e, double beta)
+{
+    const isingmc_graph *g = s->g;
+    const size_t chunk = MAX_GRID_Y * RB;
+    for (size_t r0 = 0; r0 < s->R; r0 += chunk) {
+        const size_t n = std::min(chunk, s->R - r0);
+        const dim3 grid((e - b + 255) / 256, unsigned((n + RB - 1) / RB));
+        hipLaunchKernelGGL((gen_sweep_kernel<WT, RB>), grid, dim3(256), 0, s->stream, s->d_state + r0 * g->state_words,
+                           g->gdev, b, e, s->t, s->d_keys + r0, beta, s->has_betas ? s->d_beta + r0 : nullptr, uint32_t(n));
+    }
+}
+
 static void launch_gen_timestep(isingmc_states *s, double beta)
 {
     const isingmc_graph *g = s->g;
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
         if (e == b) continue;
-        for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
-            const size_t n = std::min(MAX_GRID_Y, s->R - r0);
-            const dim3 grid((e - b + 255) / 256, unsigned(n));
-            const double *br = s->has_betas ? s->d_beta + r0 : nullptr;
-            if (g->w_is_float)
-                hipLaunchKernelGGL(gen_sweep_kernel<float>, grid, dim3(256), 0, s->stream,
-                                   s->d_state + r0 * g->state_words, g->gdev, b, e, s->t, s->d_keys + r0, beta, br);
-            else
-                hipLaunchKernelGGL(gen_sweep_kernel<double>, grid, dim3(256), 0, s->stream,
-                                   s->d_state + r0 * g->state_words, g->gdev, b, e, s->t, s->d_keys + r0, beta, br);
+        if (s->R >= GEN_RB) {
+            if (g->w_is_float) launch_gen_class<float, GEN_RB>(s, b, e, beta);
+            else launch_gen_class<double, GEN_RB>(s, b, e, beta);
+        } else {
+            if (g->w_is_float) launch_gen_class<float, 1>(s, b, e, beta);
+            else launch_gen_class<double, 1>(s, b, e, beta);
         }
     }
 }

@@ -197,3 +197,58 @@ def test_readme_three_spin_chain_energies(capi, oracle):
         st = capi.States(g, SEEDS[:1], initial_state=np.array(state, dtype=np.uint8))
         assert st.energies()[0] == e
         assert oracle.energy(ea, eb, ej, 3, np.array(state, dtype=np.uint8)) == e
+
+
+def test_many_replicas_chunked_grid(capi, oracle, exact):
+    """More replicas than one grid.y launch covers (32768): results must not depend on the chunking."""
+    W, H, R = 64, 4, 33000
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(5, R)
+    st = capi.States(g, seeds)
+    st.do_time_steps(3, 0.5)
+    packed = st.packed()
+    lat = oracle.Lat(W, H)
+    for r in (0, 1, 32767, 32768, 32999):
+        ref = lat.init(seeds[r])
+        for t in range(3):
+            lat.sweep(ref, seeds[r], t, 0.5)
+        np.testing.assert_array_equal(packed[r], ref)
+    e = st.energies()
+    assert e.shape == (R,) and e[32999] == lat.energy_mag(ref)[0]
+    # general path with more replicas than one launch of replica groups
+    ea, eb, ej = exact.square_lattice_edges(6, 4, -1.0)
+    g2 = capi.Graph(ea, eb, ej)
+    assert g2.kind == capi.KIND_GENERAL
+    st2 = capi.States(g2, seeds[:13])                                       # not a multiple of the replica block (8)
+    st2.do_time_steps(5, 0.6)
+    spins = st2.states()
+    for r in (0, 7, 8, 12):
+        _, s_ref = oracle.gen_run(ea, eb, ej, 24, seeds[r], [0.6] * 5)
+        np.testing.assert_array_equal(spins[r].astype(np.uint8), s_ref)
+
+
+def test_empty_and_degenerate_inputs(capi, exact):
+    ea, eb, ej = exact.square_lattice_edges(64, 4, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, np.zeros(0, dtype=np.uint64))                       # zero experiments
+    assert st.count == 0
+    st.do_time_steps(5, 0.3)
+    assert st.energies().shape == (0,) and st.states().shape == (0, 256)
+    st.append(9)
+    st.do_time_steps(0, 0.3)                                                # zero timesteps
+    assert st.timestep == 5 and st.count == 1
+    with pytest.raises(ValueError):
+        capi.Graph(np.zeros(0), np.zeros(0), np.zeros(0), nvars=3)          # lattice.rs:70-72
+    with pytest.raises(ValueError):
+        capi.Graph([0], [1], [float("inf")])
+    with pytest.raises(ValueError):
+        st.do_time_steps(2, float("nan"))
+    with pytest.raises(ValueError):
+        st.set_state(3, np.zeros(256, dtype=np.uint8))
+    with pytest.raises(RuntimeError):
+        capi.Graph(ea, eb, ej, device=99)
+    single = capi.Graph([0], [0], [2.5], nvars=1)                           # one self-loop: constant energy, free spin
+    s1 = capi.States(single, [1])
+    s1.do_time_steps(3, 1.0)
+    assert s1.energies()[0] == 2.5
