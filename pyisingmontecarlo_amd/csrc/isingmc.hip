@@ -744,6 +744,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     TRY(use_device(s->g->device));
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
+    if (R == 0) s->t += timesteps; // time passes for an empty container too (replicas appended later start here)
     if (R == 0 || timesteps == 0) return ISINGMC_OK;
     const bool lattice = g->kind == ISINGMC_KIND_LATTICE2D;
 
