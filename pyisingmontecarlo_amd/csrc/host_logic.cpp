@@ -254,3 +254,46 @@ uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const doub
 }
 
 } // namespace isingmc
+
+// ---- packed checkerboard planes -> one byte per spin (get_state copy-out, lattice.rs:209-211) ------------
+#include <emmintrin.h>
+namespace isingmc {
+
+// bit k of the index -> byte k of the entry
+static const uint64_t *spread_lut()
+{
+    static uint64_t lut[256];
+    static bool ready = [] {
+        for (int b = 0; b < 256; b++) {
+            uint64_t v = 0;
+            for (int k = 0; k < 8; k++) v |= uint64_t((b >> k) & 1) << (8 * k);
+            lut[b] = v;
+        }
+        return true;
+    }();
+    (void)ready;
+    return lut;
+}
+
+void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins)
+{
+    const uint64_t *lut = spread_lut();
+    const uint32_t wpr = W / 64;
+    const size_t wpp = size_t(H) * wpr;
+    for (uint32_t y = 0; y < H; y++) {
+        // colour c of row y sits at x = 2i + ((y+c)&1): even x is colour (y&1), odd x the other one
+        const uint32_t *even = words + (y & 1 ? wpp : 0) + size_t(y) * wpr;
+        const uint32_t *odd = words + (y & 1 ? 0 : wpp) + size_t(y) * wpr;
+        uint8_t *out = spins + size_t(y) * W;
+        for (uint32_t xw = 0; xw < wpr; xw++) {
+            const uint32_t we = even[xw], wo = odd[xw];
+            for (int k = 0; k < 4; k++) { // 8 + 8 bits -> 16 interleaved bytes
+                const __m128i a = _mm_cvtsi64_si128((long long)lut[(we >> (8 * k)) & 0xFF]);
+                const __m128i b = _mm_cvtsi64_si128((long long)lut[(wo >> (8 * k)) & 0xFF]);
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(out + 64 * xw + 16 * k), _mm_unpacklo_epi8(a, b));
+            }
+        }
+    }
+}
+
+} // namespace isingmc

@@ -62,4 +62,7 @@ Colouring greedy_colouring(const Adjacency &A, size_t nvars);
 uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
                        const double *slot_energy, uint32_t *perm);
 
+// packed checkerboard planes of one replica -> W*H bytes in site order (16 bytes per SSE2 store)
+void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins);
+
 } // namespace isingmc

@@ -199,20 +199,7 @@ static void pack_state(const isingmc_graph *g, const uint8_t *spins, uint32_t *w
 static void unpack_state(const isingmc_graph *g, const uint32_t *words, uint8_t *spins)
 {
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        const LatGeom &L = g->geom;
-        for (uint32_t y = 0; y < L.H; y++) {
-            const uint32_t *row0 = words + size_t(y) * L.wpr, *row1 = row0 + L.wpp;
-            uint8_t *out = spins + size_t(y) * L.W;
-            const uint32_t o0 = y & 1; // x offset of colour 0 in this row
-            for (uint32_t xw = 0; xw < L.wpr; xw++) {
-                const uint32_t w0 = row0[xw], w1 = row1[xw];
-                uint8_t *o = out + 64 * xw;
-                for (uint32_t b = 0; b < 32; b++) {
-                    o[2 * b + o0] = (w0 >> b) & 1u;
-                    o[2 * b + 1 - o0] = (w1 >> b) & 1u;
-                }
-            }
-        }
+        unpack_lattice(g->geom.W, g->geom.H, words, spins);
     } else {
         for (uint64_t i = 0; i < g->nvars; i++) spins[i] = (words[g->pos[i] >> 5] >> (g->pos[i] & 31)) & 1u;
     }
