@@ -343,14 +343,14 @@ static int lat_get(const lat_geom *g, const uint32_t *state, int y, int x)
     return (state[(size_t)c * g->wpp + (size_t)y * g->wpr + (i >> 5)] >> (i & 31)) & 1;
 }
 
-/* S2: random initial state, word w of plane c = Philox(key, (w>>2, 0, c<<8, DOM_LAT_INIT))[w&3] */
+/* S2: random initial state, word w of plane c = Philox(key, (0, w>>2, c<<8, DOM_LAT_INIT))[w&3] */
 void orc_lat_init(int W, int H, uint64_t seed, uint32_t *state)
 {
     lat_geom g = lat_make(W, H);
     for (uint32_t c = 0; c < 2; c++)
         for (size_t w = 0; w < g.wpp; w++) {
             uint32_t r[4];
-            philox_seeded(seed, (uint32_t)(w >> 2), 0, ctr2(0, c, 0), DOM_LAT_INIT, r);
+            philox_seeded(seed, 0, (uint32_t)(w >> 2), ctr2(0, c, 0), DOM_LAT_INIT, r);
             state[c * g.wpp + w] = r[w & 3];
         }
 }
@@ -417,7 +417,7 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
         for (size_t Q = 0; Q < nquads; Q++) {
             uint32_t planes[N_PLANES][4];
             for (uint32_t p = 0; p < N_PLANES; p++)
-                philox_seeded(seed, (uint32_t)Q, (uint32_t)t, ctr2(t, c, p), DOM_LAT_SWEEP,
+                philox_seeded(seed, (uint32_t)t, (uint32_t)Q, ctr2(t, c, p), DOM_LAT_SWEEP,
                               planes[p]);
             uint32_t resid[4];
             unsigned n_undecided = 0;
@@ -441,7 +441,7 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
                         else if (upre > hi) accept = 0;
                         else {
                             if ((n_undecided & 3) == 0)
-                                philox_seeded(seed, (uint32_t)Q, (uint32_t)t,
+                                philox_seeded(seed, (uint32_t)t, (uint32_t)Q,
                                               ctr2(t, c, N_PLANES + n_undecided / 4),
                                               DOM_LAT_SWEEP, resid);
                             accept = resid[n_undecided & 3] < lo;
@@ -582,9 +582,9 @@ uint32_t orc_gen_colouring(size_t n_edges, const uint64_t *ea, const uint64_t *e
 /*
  * One experiment on the general path.  state: one byte per spin in SITE order.
  * initial == NULL: S2' random start -- packed word w (positions 32w..32w+31) =
- * Philox(key, (w>>2, 0, 0, DOM_GEN_INIT))[w&3]; site i takes bit pos(i)&31 of word pos(i)>>5.
+ * Philox(key, (0, w>>2, 0, DOM_GEN_INIT))[w&3]; site i takes bit pos(i)&31 of word pos(i)>>5.
  * Timestep t (absolute, t0 + local index): colour classes in order; site i draws
- * Philox(key, (i>>1, t_lo, t_hi16<<16, DOM_GEN_SWEEP)) words 2(i&1), 2(i&1)+1 -> 53-bit u.
+ * Philox(key, (t_lo, i>>1, t_hi16<<16, DOM_GEN_SWEEP)) words 2(i&1), 2(i&1)+1 -> 53-bit u.
  */
 void orc_gen_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
                  size_t nvars, const double *biases, uint64_t seed, const uint8_t *initial,
@@ -598,7 +598,7 @@ void orc_gen_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const d
         for (size_t i = 0; i < nvars; i++) {
             size_t p = G.pos[i], w = p >> 5;
             uint32_t r[4];
-            philox_seeded(seed, (uint32_t)(w >> 2), 0, 0, DOM_GEN_INIT, r);
+            philox_seeded(seed, 0, (uint32_t)(w >> 2), 0, DOM_GEN_INIT, r);
             state[i] = (uint8_t)((r[w & 3] >> (p & 31)) & 1u);
         }
     /* (t0 != 0 with initial == NULL: continue from the state already in `state`) */
@@ -618,7 +618,7 @@ void orc_gen_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const d
                 int accept = dE <= 0.0;
                 if (!accept) {
                     uint32_t r[4];
-                    philox_seeded(seed, (uint32_t)(i >> 1), (uint32_t)t, ctr2(t, 0, 0),
+                    philox_seeded(seed, (uint32_t)t, (uint32_t)(i >> 1), ctr2(t, 0, 0),
                                   DOM_GEN_SWEEP, r);
                     uint64_t x = ((uint64_t)r[2 * (i & 1) + 1] << 32) | r[2 * (i & 1)];
                     double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);

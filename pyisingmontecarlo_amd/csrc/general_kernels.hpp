@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gen_sweep_kernel(
             flip = dE <= 0.0;
             if (!flip) {
                 const uint4 rnd =
-                    philox4x32_10(make_uint4(site >> 1, uint32_t(t), ctr2(t, 0, 0), DOM_GEN_SWEEP), keys[r]);
+                    philox4x32_10(make_uint4(uint32_t(t), site >> 1, ctr2(t, 0, 0), DOM_GEN_SWEEP), keys[r]);
                 const uint64_t x = (site & 1u) ? (uint64_t(rnd.w) << 32 | rnd.z) : (uint64_t(rnd.y) << 32 | rnd.x);
                 const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
                 flip = u < det_exp(-beta * dE);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void gen_sweep_kernel(
     }
 }
 
-// random start: packed word w = Philox(key, (w>>2, 0, 0, "GENI"))[w&3], padding bits cleared
+// random start: packed word w = Philox(key, (0, w>>2, 0, "GENI"))[w&3], padding bits cleared
 __global__ __launch_bounds__(256) void gen_init_kernel(uint32_t *__restrict__ state,
                                                        const GenGraphDev G,
                                                        const uint2 *__restrict__ keys,
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void gen_init_kernel(uint32_t *__restrict__ st
     const uint32_t r = first_replica + blockIdx.y;
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
     if (w >= G.n_words) return;
-    const uint4 rnd = philox4x32_10(make_uint4(w >> 2, 0, 0, DOM_GEN_INIT), keys[r]);
+    const uint4 rnd = philox4x32_10(make_uint4(0, w >> 2, 0, DOM_GEN_INIT), keys[r]);
     uint32_t v = (w & 3) == 0 ? rnd.x : (w & 3) == 1 ? rnd.y : (w & 3) == 2 ? rnd.z : rnd.w;
     uint32_t valid = 0;
     for (int b = 0; b < 32; b++) valid |= uint32_t(G.site[32 * w + b] != PAD_SITE) << b;

@@ -313,6 +313,16 @@ static int build_lattice(isingmc_graph *g, const Lattice2D &L)
     G.wpp = G.H * G.wpr;
     G.nquads = G.wpp / 4;
     g->vec = G.wpr % 4 == 0;
+    G.cols_log2 = -1;
+    if (g->vec) { // division-free, parity-uniform thread mapping (thread_to_quad)
+        const uint32_t cols = G.wpr / 4;
+        if ((cols & (cols - 1)) == 0) {
+            int cl = 0;
+            while ((1u << cl) < cols) cl++;
+            const uint32_t rows_per_pair = cl >= 6 ? 1 : 2 * (64u >> cl);
+            if (G.H % rows_per_pair == 0 && G.nquads % 64 == 0) G.cols_log2 = cl;
+        }
+    }
     g->jabs = L.jabs;
     g->uniform_sign = L.uniform_sign;
     g->jneg_uniform = L.jpos_uniform ? 0u : 0xFFFFFFFFu;

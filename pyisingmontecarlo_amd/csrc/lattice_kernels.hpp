@@ -22,6 +22,7 @@ struct LatGeom {
     uint32_t wpr;    // words per colour-row = W / 64
     uint32_t wpp;    // words per plane = H * wpr
     uint32_t nquads; // wpp / 4
+    int32_t cols_log2; // log2(quads per row) when the division-free, parity-uniform thread mapping applies, else -1
 };
 
 struct LatThr {
@@ -44,16 +45,40 @@ struct QuadNbr {
     uint32_t up[4], dn[4], ce[4], si[4];
 };
 
-// Loads the 4 own words and the neighbour words of quad Q in plane `colour`.
+// Thread -> quad.  With 2^k quads per row the mapping needs no division and keeps the row parity
+// (which decides whether the side neighbour is i+1 or i-1) uniform per wavefront: a pair of waves
+// shares 2*rpw consecutive rows, wave 0 takes the even ones, wave 1 the odd ones (rpw = 64 >> k rows
+// per wave; for k >= 6 a wave never leaves its row).  Any bijection is valid: the Philox counters are
+// functions of the quad index, never of the thread index.
+__device__ __forceinline__ void thread_to_quad(const LatGeom &g, uint32_t gid, uint32_t &Q, uint32_t &y,
+                                               uint32_t &xw)
+{
+    if (g.cols_log2 >= 0) {
+        const uint32_t cl = uint32_t(g.cols_log2), col = gid & ((1u << cl) - 1);
+        if (cl >= 6) {
+            y = gid >> cl;
+        } else {
+            const uint32_t wave = gid >> 6, j = (gid & 63u) >> cl;
+            y = ((wave >> 1) << (7 - cl)) + 2 * j + (wave & 1u);
+        }
+        Q = (y << cl) + col;
+        xw = 4 * col;
+    } else {
+        Q = gid;
+        y = (4 * Q) / g.wpr;
+        xw = 4 * Q - y * g.wpr;
+    }
+}
+
+// Loads the 4 own words and the neighbour words of quad Q (row y, first word xw) in plane `colour`.
 template <bool VEC>
 __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane,
                                           const uint32_t *__restrict__ oth_plane, const LatGeom &g,
-                                          uint32_t colour, uint32_t Q, uint32_t own[4], QuadNbr &n,
-                                          uint32_t widx[4])
+                                          uint32_t colour, uint32_t Q, uint32_t y, uint32_t xw, uint32_t own[4],
+                                          QuadNbr &n, uint32_t widx[4])
 {
     if constexpr (VEC) { // wpr % 4 == 0: the quad lies inside one row
         const uint32_t w0 = 4 * Q;
-        const uint32_t y = w0 / g.wpr, xw = w0 - y * g.wpr;
         const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
         const uint32_t row = y * g.wpr;
         const uint4 o4 = *reinterpret_cast<const uint4 *>(own_plane + w0);
@@ -64,7 +89,9 @@ __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane
         n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
         n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
         n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
-        if ((y + colour) & 1) { // horizontal neighbours have compact indices i and i+1
+        // wave-uniform under the 2^k mapping (scalar branch); per-lane otherwise
+        const bool odd = g.cols_log2 >= 0 ? bool(__builtin_amdgcn_readfirstlane((y + colour) & 1u)) : bool((y + colour) & 1u);
+        if (odd) { // horizontal neighbours have compact indices i and i+1
             const uint32_t nxt = oth_plane[row + (xw + 4 == g.wpr ? 0 : xw + 4)];
             n.si[0] = (c4.x >> 1) | (c4.y << 31);
             n.si[1] = (c4.y >> 1) | (c4.z << 31);
@@ -83,19 +110,19 @@ __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t w = 4 * Q + q;
-            const uint32_t y = w / g.wpr, xw = w - y * g.wpr;
-            const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
-            const uint32_t row = y * g.wpr;
+            const uint32_t yy = w / g.wpr, xx = w - yy * g.wpr;
+            const uint32_t yu = (yy == 0 ? g.H : yy) - 1, yd = (yy + 1 == g.H) ? 0 : yy + 1;
+            const uint32_t row = yy * g.wpr;
             widx[q] = w;
             own[q] = own_plane[w];
             n.ce[q] = oth_plane[w];
-            n.up[q] = oth_plane[yu * g.wpr + xw];
-            n.dn[q] = oth_plane[yd * g.wpr + xw];
-            if ((y + colour) & 1) {
-                const uint32_t nxt = oth_plane[row + (xw + 1 == g.wpr ? 0 : xw + 1)];
+            n.up[q] = oth_plane[yu * g.wpr + xx];
+            n.dn[q] = oth_plane[yd * g.wpr + xx];
+            if ((yy + colour) & 1) {
+                const uint32_t nxt = oth_plane[row + (xx + 1 == g.wpr ? 0 : xx + 1)];
                 n.si[q] = (n.ce[q] >> 1) | (nxt << 31);
             } else {
-                const uint32_t prv = oth_plane[row + (xw == 0 ? g.wpr : xw) - 1];
+                const uint32_t prv = oth_plane[row + (xx == 0 ? g.wpr : xx) - 1];
                 n.si[q] = (n.ce[q] << 1) | (prv >> 31);
             }
         }
@@ -131,8 +158,10 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform)
 {
     const uint32_t r = blockIdx.y;
-    const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
-    if (Q >= g.nquads) return;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= g.nquads) return;
+    uint32_t Q, qy, qxw;
+    thread_to_quad(g, gid, Q, qy, qxw);
 
     const LatThr thr = thr_replica ? thr_replica[r] : thr_uniform;
     const uint2 key = keys[r];
@@ -142,7 +171,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
 
     uint32_t own[4], widx[4];
     QuadNbr n;
-    load_quad<VEC>(own_plane, oth_plane, g, colour, Q, own, n, widx);
+    load_quad<VEC>(own_plane, oth_plane, g, colour, Q, qy, qxw, own, n, widx);
 
     // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
     uint32_t eq4[4], lt[4], und[4], le2[4];
@@ -163,7 +192,9 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     }
 
     // N_PLANES bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
-    const uint32_t c0 = Q, c1 = uint32_t(t);
+    // counter = (t_lo, quad, ctr2, domain): the lane-varying quad index sits in a NON-multiplied word, which
+    // keeps round 1 of every call on the scalar unit and rounds 2-3 at one vector multiply (16 instead of 18)
+    const uint32_t c0 = uint32_t(t), c1 = Q;
 #pragma unroll
     for (int p = 0; p < N_PLANES; p++) {
         const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, p), DOM_LAT_SWEEP), key);
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     }
 }
 
-// Random initial configuration: word w of plane c = Philox(key, (w>>2, 0, c<<8, "LATI"))[w&3].
+// Random initial configuration: word w of plane c = Philox(key, (0, w>>2, c<<8, "LATI"))[w&3].
 __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
                                                        const uint2 *__restrict__ keys,
                                                        const uint32_t first_replica)
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ st
     const uint32_t Q = blockIdx.x * 256 + threadIdx.x;
     if (Q >= 2 * g.nquads) return;
     const uint32_t c = Q >= g.nquads, q = Q - c * g.nquads;
-    const uint4 rnd = philox4x32_10(make_uint4(q, 0, ctr2(0, c, 0), DOM_LAT_INIT), keys[r]);
+    const uint4 rnd = philox4x32_10(make_uint4(0, q, ctr2(0, c, 0), DOM_LAT_INIT), keys[r]);
     *reinterpret_cast<uint4 *>(state + size_t(r) * 2 * g.wpp + size_t(c) * g.wpp + 4 * size_t(q)) = rnd;
 }
 
@@ -244,11 +275,12 @@ __global__ __launch_bounds__(256) void lat_measure_kernel(
     uint32_t sat = 0, up = 0;
     const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
     for (uint32_t i = 0; i < MEASURE_QUADS_PER_THREAD; i++) {
-        const uint32_t Q = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
-        if (Q >= g.nquads) break;
-        uint32_t own[4], widx[4];
+        const uint32_t gid = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
+        if (gid >= g.nquads) break;
+        uint32_t Q, qy, qxw, own[4], widx[4];
+        thread_to_quad(g, gid, Q, qy, qxw);
         QuadNbr n;
-        load_quad<VEC>(p0, p0 + g.wpp, g, 0, Q, own, n, widx);
+        load_quad<VEC>(p0, p0 + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t a0, a1, a2, a3;
