@@ -622,9 +622,13 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
     const isingmc_graph *g = s->g;
     for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
         const size_t n = std::min(MAX_GRID_Y, s->R - r0);
-        hipLaunchKernelGGL((lat_sweep_kernel<VEC, PMJ>), lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
-                           s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
-                           s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
+        const auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
+                               s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                               s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
+        };
+        if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
+        else launch(lat_sweep_kernel<VEC, PMJ, false>);
     }
 }
 

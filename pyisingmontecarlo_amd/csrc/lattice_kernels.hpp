@@ -50,10 +50,11 @@ struct QuadNbr {
 // shares 2*rpw consecutive rows, wave 0 takes the even ones, wave 1 the odd ones (rpw = 64 >> k rows
 // per wave; for k >= 6 a wave never leaves its row).  Any bijection is valid: the Philox counters are
 // functions of the quad index, never of the thread index.
+template <bool UNI>
 __device__ __forceinline__ void thread_to_quad(const LatGeom &g, uint32_t gid, uint32_t &Q, uint32_t &y,
                                                uint32_t &xw)
 {
-    if (g.cols_log2 >= 0) {
+    if constexpr (UNI) {
         const uint32_t cl = uint32_t(g.cols_log2), col = gid & ((1u << cl) - 1);
         if (cl >= 6) {
             y = gid >> cl;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void thread_to_quad(const LatGeom &g, uint32_t gid, u
 }
 
 // Loads the 4 own words and the neighbour words of quad Q (row y, first word xw) in plane `colour`.
-template <bool VEC>
+template <bool VEC, bool UNI>
 __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane,
                                           const uint32_t *__restrict__ oth_plane, const LatGeom &g,
                                           uint32_t colour, uint32_t Q, uint32_t y, uint32_t xw, uint32_t own[4],
@@ -80,26 +81,27 @@ __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane
     if constexpr (VEC) { // wpr % 4 == 0: the quad lies inside one row
         const uint32_t w0 = 4 * Q;
         const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
-        const uint32_t row = y * g.wpr;
+        // horizontal neighbours have compact indices {i, i+1} on odd rows of this colour, {i-1, i} on even
+        // ones: wave-uniform under the 2^k mapping (scalar branch), per-lane otherwise
+        bool odd = (y + colour) & 1u;
+        if constexpr (UNI) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd));
+        const uint32_t sx = odd ? (xw + 4 == g.wpr ? 0 : xw + 4) : (xw == 0 ? g.wpr : xw) - 1;
         const uint4 o4 = *reinterpret_cast<const uint4 *>(own_plane + w0);
         const uint4 c4 = *reinterpret_cast<const uint4 *>(oth_plane + w0);
         const uint4 u4 = *reinterpret_cast<const uint4 *>(oth_plane + yu * g.wpr + xw);
         const uint4 d4 = *reinterpret_cast<const uint4 *>(oth_plane + yd * g.wpr + xw);
+        const uint32_t sw = oth_plane[y * g.wpr + sx]; // issued with the other loads, not behind a branch
         own[0] = o4.x; own[1] = o4.y; own[2] = o4.z; own[3] = o4.w;
         n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
         n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
         n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
-        // wave-uniform under the 2^k mapping (scalar branch); per-lane otherwise
-        const bool odd = g.cols_log2 >= 0 ? bool(__builtin_amdgcn_readfirstlane((y + colour) & 1u)) : bool((y + colour) & 1u);
-        if (odd) { // horizontal neighbours have compact indices i and i+1
-            const uint32_t nxt = oth_plane[row + (xw + 4 == g.wpr ? 0 : xw + 4)];
+        if (odd) {
             n.si[0] = (c4.x >> 1) | (c4.y << 31);
             n.si[1] = (c4.y >> 1) | (c4.z << 31);
             n.si[2] = (c4.z >> 1) | (c4.w << 31);
-            n.si[3] = (c4.w >> 1) | (nxt << 31);
-        } else { // i-1 and i
-            const uint32_t prv = oth_plane[row + (xw == 0 ? g.wpr : xw) - 1];
-            n.si[0] = (c4.x << 1) | (prv >> 31);
+            n.si[3] = (c4.w >> 1) | (sw << 31);
+        } else {
+            n.si[0] = (c4.x << 1) | (sw >> 31);
             n.si[1] = (c4.y << 1) | (c4.x >> 31);
             n.si[2] = (c4.z << 1) | (c4.y >> 31);
             n.si[3] = (c4.w << 1) | (c4.z >> 31);
@@ -151,7 +153,7 @@ __device__ __forceinline__ void bond_masks(const uint32_t own, const QuadNbr &n,
     }
 }
 
-template <bool VEC, bool PMJ>
+template <bool VEC, bool PMJ, bool UNI>
 __global__ __launch_bounds__(256) void lat_sweep_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t,
     const uint2 *__restrict__ keys, const LatThr thr_uniform, const LatThr *__restrict__ thr_replica,
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= g.nquads) return;
     uint32_t Q, qy, qxw;
-    thread_to_quad(g, gid, Q, qy, qxw);
+    thread_to_quad<UNI>(g, gid, Q, qy, qxw);
 
     const LatThr thr = thr_replica ? thr_replica[r] : thr_uniform;
     const uint2 key = keys[r];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
 
     uint32_t own[4], widx[4];
     QuadNbr n;
-    load_quad<VEC>(own_plane, oth_plane, g, colour, Q, qy, qxw, own, n, widx);
+    load_quad<VEC, UNI>(own_plane, oth_plane, g, colour, Q, qy, qxw, own, n, widx);
 
     // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
     uint32_t eq4[4], lt[4], und[4], le2[4];
@@ -278,9 +280,9 @@ __global__ __launch_bounds__(256) void lat_measure_kernel(
         const uint32_t gid = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
         if (gid >= g.nquads) break;
         uint32_t Q, qy, qxw, own[4], widx[4];
-        thread_to_quad(g, gid, Q, qy, qxw);
+        thread_to_quad<false>(g, gid, Q, qy, qxw);
         QuadNbr n;
-        load_quad<VEC>(p0, p0 + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
+        load_quad<VEC, false>(p0, p0 + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t a0, a1, a2, a3;
