@@ -19,6 +19,8 @@ struct GenGraphDev {
     const void *w;           // couplings, float (when lossless) or double
     const double *bias;      // per position, or nullptr (all zero)
     const uint32_t *site;    // original site id per position, PAD_SITE on padding
+    const uint32_t *class_base; // n_colours + 1 positions (device copy of the colour-class boundaries)
+    uint32_t n_colours;
     uint32_t n_pos;          // multiple of 64
     uint32_t n_words;        // n_pos / 32
 };
@@ -196,6 +198,90 @@ __global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) { out_e[r] = se[0]; out_m[r] = sm[0]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident variant for small graphs (packed state <= GEN_RESIDENT_MAX_BYTES): one workgroup owns
+// one replica for `timesteps` whole timesteps, all colour classes, with the spins in LDS and a
+// workgroup barrier between classes -- instead of n_colours launches per timestep.  Same per-site
+// arithmetic and Philox counters as gen_sweep_kernel => same configurations.
+// energies_out (optional): E after every timestep, [replica][timesteps], reduced in a fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t GEN_RESIDENT_MAX_BYTES = 32 * 1024;
+
+template <typename WT>
+__global__ __launch_bounds__(1024) void gen_resident_kernel(
+    uint32_t *__restrict__ state, const GenGraphDev G, const uint64_t t0, const uint32_t timesteps,
+    const uint2 *__restrict__ keys, const double *__restrict__ beta_steps, const uint32_t beta_stride,
+    const double *__restrict__ beta_replica, double *__restrict__ energies_out, const double self_energy)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t st[];
+    __shared__ double red[16];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *mine = state + size_t(r) * G.n_words;
+    for (uint32_t i = tid; i < G.n_words; i += nthreads) st[i] = mine[i];
+    const uint2 key = keys[r];
+    const WT *w = static_cast<const WT *>(G.w);
+    __syncthreads();
+    for (uint32_t k = 0; k < timesteps; k++) {
+        const uint64_t t = t0 + k;
+        const double beta = beta_replica ? beta_replica[r] : beta_steps[size_t(k) * beta_stride];
+        for (uint32_t c = 0; c < G.n_colours; c++) {
+            const uint32_t begin = G.class_base[c], end = G.class_base[c + 1];
+            for (uint32_t p = begin + tid; p < end; p += nthreads) { // whole waves: class sizes are multiples of 64
+                const uint32_t site = G.site[p];
+                bool flip = false;
+                if (site != PAD_SITE) {
+                    double field = 0.0;
+                    for (uint32_t e = G.rowptr[p], ee = G.rowptr[p + 1]; e < ee; e++) {
+                        const uint32_t q = G.nbr[e];
+                        const double j = double(w[e]);
+                        field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
+                    }
+                    const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
+                    const double dE = 2.0 * si * ((G.bias ? G.bias[p] : 0.0) - field);
+                    flip = dE <= 0.0;
+                    if (!flip) {
+                        const uint4 rnd = philox4x32_10(make_uint4(uint32_t(t), site >> 1, ctr2(t, 0, 0), DOM_GEN_SWEEP), key);
+                        const uint64_t x = (site & 1u) ? (uint64_t(rnd.w) << 32 | rnd.z) : (uint64_t(rnd.y) << 32 | rnd.x);
+                        const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
+                        flip = u < det_exp(-beta * dE);
+                    }
+                }
+                const unsigned long long mask = __ballot(flip);
+                if ((tid & 63) == 0 && mask) {
+                    st[p >> 5] ^= uint32_t(mask);
+                    st[(p >> 5) + 1] ^= uint32_t(mask >> 32);
+                }
+            }
+            __syncthreads();
+        }
+        if (energies_out) {
+            double e = 0.0;
+            for (uint32_t p = tid; p < G.n_pos; p += nthreads) {
+                if (G.site[p] == PAD_SITE) continue;
+                double field = 0.0;
+                for (uint32_t ed = G.rowptr[p], ee = G.rowptr[p + 1]; ed < ee; ed++) {
+                    const uint32_t q = G.nbr[ed];
+                    const double j = double(w[ed]);
+                    field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
+                }
+                const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
+                e += si * (0.5 * field - (G.bias ? G.bias[p] : 0.0));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+            if ((tid & 63) == 0) red[tid >> 6] = e;
+            __syncthreads();
+            if (tid == 0) {
+                double sum = 0.0;
+                for (uint32_t wv = 0; wv < (nthreads + 63) / 64; wv++) sum += red[wv];
+                energies_out[size_t(r) * timesteps + k] = sum + self_energy;
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < G.n_words; i += nthreads) mine[i] = st[i];
 }
 
 } // namespace isingmc

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -392,6 +393,11 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
     TRY(graph_upload(g, &D.rowptr, rowptr));
     TRY(graph_upload(g, &D.nbr, nbr));
     TRY(graph_upload(g, &D.site, site));
+    {
+        std::vector<uint32_t> cb(C.class_base.begin(), C.class_base.end());
+        TRY(graph_upload(g, &D.class_base, cb));
+        D.n_colours = C.n_colours;
+    }
     g->w_is_float = lossless;
     if (lossless) { // stream 4-byte couplings when that loses nothing (e.g. J = +-1)
         std::vector<float> wf(w.begin(), w.end());
@@ -733,6 +739,13 @@ static int measure(isingmc_states *s, double *energies, int64_t *mags)
     return ISINGMC_OK;
 }
 
+// ISINGMC_DISABLE_RESIDENT=1: always use the per-colour launches (A/B runs, parity tests of both paths)
+static bool resident_disabled()
+{
+    const char *e = std::getenv("ISINGMC_DISABLE_RESIDENT");
+    return e && e[0] && e[0] != '0';
+}
+
 static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
                      double *energies_per_step, float *device_ms)
 {
@@ -751,19 +764,72 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
 
     // per-step energies on the lattice path: integer counters per (step, replica), converted at the
     // end of each chunk; on the general path one measure() per step.
-    const size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
+    // small lattices: one LDS-resident launch per chunk of timesteps instead of two launches per timestep
+    const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && !resident_disabled();
+    size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
+    const bool gen_resident = !lattice && g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && !resident_disabled();
+    if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
+    double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
+    if (gen_resident) {
+        if (!s->has_betas) TRY(dev_alloc(&d_beta_steps, beta_stride ? chunk : 1));
+        if (energies_per_step) TRY(dev_alloc(&d_gen_energies, chunk * R));
+    }
     unsigned long long *d_steps = nullptr;
+    LatThr *d_thr_steps = nullptr;
     std::vector<unsigned long long> h_steps;
+    std::vector<LatThr> h_thr;
     if (energies_per_step && lattice) {
         TRY(dev_alloc(&d_steps, chunk * R * 2));
         h_steps.resize(chunk * R * 2);
     }
+    if (resident && !s->has_betas) TRY(dev_alloc(&d_thr_steps, beta_stride ? chunk : 1));
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
         if (d_steps) HIP_TRY(hipMemsetAsync(d_steps, 0, nk * R * 2 * sizeof(unsigned long long), s->stream));
-        for (size_t k = k0; k < k0 + nk; k++) {
+        if (resident) {
+            if (!s->has_betas) {
+                h_thr.resize(beta_stride ? nk : 1);
+                for (size_t k = 0; k < h_thr.size(); k++) h_thr[k] = lattice_thresholds(betas[(k0 + k) * beta_stride], g->jabs);
+                HIP_TRY(hipMemcpyAsync(d_thr_steps, h_thr.data(), h_thr.size() * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
+            }
+            const unsigned threads = unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            const auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), g->state_words * sizeof(uint32_t), s->stream,
+                                   s->d_state, g->geom, s->t, uint32_t(nk), s->d_keys, d_thr_steps, uint32_t(beta_stride ? 1 : 0),
+                                   s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform, d_steps, uint32_t(R));
+            };
+            if (g->vec) { if (g->uniform_sign) launch(lat_resident_kernel<true, false>); else launch(lat_resident_kernel<true, true>); }
+            else { if (g->uniform_sign) launch(lat_resident_kernel<false, false>); else launch(lat_resident_kernel<false, true>); }
+            s->t += nk;
+            if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
+        }
+        if (gen_resident) {
+            const size_t nb = beta_stride ? nk : 1;
+            if (!s->has_betas) HIP_TRY(hipMemcpyAsync(d_beta_steps, betas + k0 * beta_stride, nb * sizeof(double), hipMemcpyHostToDevice, s->stream));
+            unsigned threads = 64;
+            for (uint32_t c = 0; c < g->n_colours; c++)
+                threads = std::max<unsigned>(threads, unsigned(std::min<uint64_t>(1024, g->class_base[c + 1] - g->class_base[c])));
+            const auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), g->state_words * sizeof(uint32_t), s->stream,
+                                   s->d_state, g->gdev, s->t, uint32_t(nk), s->d_keys, d_beta_steps, uint32_t(beta_stride ? 1 : 0),
+                                   s->has_betas ? s->d_beta : nullptr, d_gen_energies, g->self_energy);
+            };
+            if (g->w_is_float) launch(gen_resident_kernel<float>); else launch(gen_resident_kernel<double>);
+            s->t += nk;
+            if (d_gen_energies) {
+                std::vector<double> he(nk * R);
+                hipError_t err = hipMemcpyAsync(he.data(), d_gen_energies, he.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+                if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+                if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+                for (size_t r = 0; r < R; r++)
+                    for (size_t k = 0; k < nk; k++) energies_per_step[r * timesteps + k0 + k] = he[r * nk + k];
+            } else if (k0 + nk < timesteps) {
+                HIP_TRY(hipStreamSynchronize(s->stream));
+            }
+        }
+        for (size_t k = k0; k < k0 + nk && !resident && !gen_resident; k++) {
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
             if (lattice) {
                 const LatThr thr = lattice_thresholds(beta, g->jabs);
@@ -798,6 +864,9 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
     }
     if (d_steps) (void)hipFree(d_steps);
+    if (d_thr_steps || d_beta_steps || d_gen_energies) (void)hipStreamSynchronize(s->stream);
+    for (void *p : {(void *)d_thr_steps, (void *)d_beta_steps, (void *)d_gen_energies})
+        if (p) (void)hipFree(p);
     if (rc != ISINGMC_OK) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -153,23 +153,17 @@ __device__ __forceinline__ void bond_masks(const uint32_t own, const QuadNbr &n,
     }
 }
 
+// One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
+// plane `own_plane`, reading its neighbours from `oth_plane`.  The planes may live in HBM (sweep kernel)
+// or in LDS (resident kernel): the function only sees pointers.
 template <bool VEC, bool PMJ, bool UNI>
-__global__ __launch_bounds__(256) void lat_sweep_kernel(
-    uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t,
-    const uint2 *__restrict__ keys, const LatThr thr_uniform, const LatThr *__restrict__ thr_replica,
-    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform)
+__device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, const uint32_t *__restrict__ oth_plane,
+                                            const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
+                                            const LatThr thr, const uint32_t *__restrict__ jn,
+                                            const uint32_t jneg_uniform, const uint32_t gid)
 {
-    const uint32_t r = blockIdx.y;
-    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= g.nquads) return;
     uint32_t Q, qy, qxw;
     thread_to_quad<UNI>(g, gid, Q, qy, qxw);
-
-    const LatThr thr = thr_replica ? thr_replica[r] : thr_uniform;
-    const uint2 key = keys[r];
-    uint32_t *own_plane = state + size_t(r) * 2 * g.wpp + size_t(colour) * g.wpp;
-    const uint32_t *oth_plane = state + size_t(r) * 2 * g.wpp + size_t(1 - colour) * g.wpp;
-    const uint32_t *jn = PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr;
 
     uint32_t own[4], widx[4];
     QuadNbr n;
@@ -246,6 +240,21 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     }
 }
 
+template <bool VEC, bool PMJ, bool UNI>
+__global__ __launch_bounds__(256) void lat_sweep_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t,
+    const uint2 *__restrict__ keys, const LatThr thr_uniform, const LatThr *__restrict__ thr_replica,
+    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= g.nquads) return;
+    uint32_t *own_plane = state + size_t(r) * 2 * g.wpp + size_t(colour) * g.wpp;
+    const uint32_t *oth_plane = state + size_t(r) * 2 * g.wpp + size_t(1 - colour) * g.wpp;
+    update_quad<VEC, PMJ, UNI>(own_plane, oth_plane, g, colour, t, keys[r], thr_replica ? thr_replica[r] : thr_uniform,
+                               PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid);
+}
+
 // Random initial configuration: word w of plane c = Philox(key, (0, w>>2, c<<8, "LATI"))[w&3].
 __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
                                                        const uint2 *__restrict__ keys,
@@ -305,6 +314,76 @@ __global__ __launch_bounds__(256) void lat_measure_kernel(
         atomicAdd(out + size_t(r) * out_stride, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
         atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident kernel for small lattices (a replica's two planes fit in LDS_RESIDENT_MAX_BYTES).
+// One workgroup owns one replica for `timesteps` whole timesteps: the planes are read from HBM once,
+// every half-sweep runs out of LDS with a workgroup barrier between the colours, and they are written
+// back once.  This removes the two kernel launches per timestep that bound small lattices (10 us per
+// step whatever the size); the Philox counters depend on (quad, timestep, colour) only, so the
+// configurations are bit-identical to the per-colour launches of lat_sweep_kernel.
+// steps_out (optional): satisfied bonds / up spins after every timestep, [step][replica][2].
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t LDS_RESIDENT_MAX_BYTES = 64 * 1024;
+
+template <bool VEC, bool PMJ>
+__global__ __launch_bounds__(1024) void lat_resident_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint64_t t0, const uint32_t timesteps,
+    const uint2 *__restrict__ keys, const LatThr *__restrict__ thr_steps, const uint32_t thr_stride,
+    const LatThr *__restrict__ thr_replica, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
+    unsigned long long *__restrict__ steps_out, const uint32_t n_replicas)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t planes[]; // plane 0 then plane 1
+    __shared__ uint32_t red[2][16];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *mine = state + size_t(r) * 2 * g.wpp;
+    for (uint32_t i = tid; i < g.wpp / 2; i += nthreads) // 2*wpp words = wpp/2 uint4
+        reinterpret_cast<uint4 *>(planes)[i] = reinterpret_cast<const uint4 *>(mine)[i];
+    const uint2 key = keys[r];
+    __syncthreads();
+    for (uint32_t k = 0; k < timesteps; k++) {
+        const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
+        for (uint32_t colour = 0; colour < 2; colour++) {
+            for (uint32_t gid = tid; gid < g.nquads; gid += nthreads)
+                update_quad<VEC, PMJ, false>(planes + colour * g.wpp, planes + (1 - colour) * g.wpp, g, colour, t0 + k,
+                                             key, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform,
+                                             gid);
+            __syncthreads();
+        }
+        if (steps_out) { // get_energy after every timestep (lattice.rs:454), same sums as lat_measure_kernel
+            uint32_t sat = 0, up = 0;
+            for (uint32_t gid = tid; gid < g.nquads; gid += nthreads) {
+                uint32_t Q, qy, qxw, own[4], widx[4];
+                thread_to_quad<false>(g, gid, Q, qy, qxw);
+                QuadNbr n;
+                load_quad<VEC, false>(planes, planes + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t a0, a1, a2, a3;
+                    bond_masks<PMJ>(own[q], n, q, jneg, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+                    sat += __popc(a0) + __popc(a1) + __popc(a2) + __popc(a3);
+                    up += __popc(own[q]) + __popc(n.ce[q]);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sat += __shfl_xor(sat, off);
+                up += __shfl_xor(up, off);
+            }
+            if ((tid & 63) == 0) { red[0][tid >> 6] = sat; red[1][tid >> 6] = up; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long s = 0, u = 0;
+                for (uint32_t w = 0; w < (nthreads + 63) / 64; w++) { s += red[0][w]; u += red[1][w]; }
+                steps_out[(size_t(k) * n_replicas + r) * 2] = s;
+                steps_out[(size_t(k) * n_replicas + r) * 2 + 1] = u;
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < g.wpp / 2; i += nthreads)
+        reinterpret_cast<uint4 *>(mine)[i] = reinterpret_cast<const uint4 *>(planes)[i];
 }
 
 } // namespace isingmc

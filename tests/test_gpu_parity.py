@@ -252,3 +252,45 @@ def test_empty_and_degenerate_inputs(capi, exact):
     s1 = capi.States(single, [1])
     s1.do_time_steps(3, 1.0)
     assert s1.energies()[0] == 2.5
+
+
+@pytest.mark.parametrize("W,H,pm", [(64, 64, False), (128, 32, True), (256, 64, False), (512, 128, True), (64, 4, False)])
+def test_resident_kernel_equals_per_colour_launches(capi, exact, monkeypatch, W, H, pm):
+    """Small lattices run T timesteps inside one LDS-resident launch; the per-colour launch path
+    (ISINGMC_DISABLE_RESIDENT=1) must give the same bits, energies per step included."""
+    ea, eb, ej = exact.square_lattice_edges(W, H, 1.0 if pm else -1.0, np.random.default_rng(3) if pm else None)
+    betas = np.linspace(0.2, 0.9, 7)
+    out = []
+    for disable in ("0", "1"):
+        monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", disable)
+        g = capi.Graph(ea, eb, ej)
+        st = capi.States(g, SEEDS)
+        eps = st.do_time_steps(7, betas, per_step_energies=True)
+        st.do_time_steps(5, 0.4407)
+        st.set_betas([0.3, 0.5, 0.7])
+        eps2 = st.do_time_steps(4, per_step_energies=True)
+        out.append((st.packed(), eps, eps2, st.energies(), st.magnetisations(), st.timestep))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_general_resident_kernel_equals_per_class_launches(capi, oracle, monkeypatch):
+    rng = np.random.default_rng(21)
+    n, m = 500, 1600
+    ea = rng.integers(0, n, m).astype(np.uint64)
+    eb = rng.integers(0, n, m).astype(np.uint64)
+    ej = rng.normal(size=m)
+    biases = rng.normal(size=n) * 0.3
+    betas = np.linspace(0.1, 1.2, 9)
+    out = []
+    for disable in ("0", "1"):
+        monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", disable)
+        g = capi.Graph(ea, eb, ej, nvars=n, biases=biases)
+        st = capi.States(g, SEEDS)
+        eps = st.do_time_steps(9, betas, per_step_energies=True)
+        st.set_betas([0.3, 0.6, 0.9])
+        st.do_time_steps(6)
+        out.append((st.states(), eps, st.energies()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12, atol=1e-9)

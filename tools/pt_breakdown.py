@@ -27,3 +27,8 @@ for (W, H, R) in ((64, 64, 64), (256, 256, 64), (512, 512, 256)):
     g2 = _capi.Graph(*square(W, H), nvars=W*H); s2 = _capi.States(g2, _capi.make_seeds(1, R)); s2.do_time_steps(20, 0.4)
     t0 = time.perf_counter(); s2.do_time_steps(500, 0.4); dt = time.perf_counter() - t0
     print(f"{W}x{H} R={R}: {dt*1e6/500:.1f} us/step, {R*W*H*500/dt:.3e} attempts/s")
+# general path, tiny graphs (BASELINE c1 = 16x16, 4 experiments)
+for (W, H, R) in ((16, 16, 4), (16, 16, 256), (32, 32, 64)):
+    g2 = _capi.Graph(*square(W, H), nvars=W*H); s2 = _capi.States(g2, _capi.make_seeds(1, R)); s2.do_time_steps(20, 0.3)
+    t0 = time.perf_counter(); s2.do_time_steps(1000, 0.3); dt = time.perf_counter() - t0
+    print(f"general {W}x{H} R={R}: {dt*1e6/1000:.1f} us/step, {R*W*H*1000/dt:.3e} attempts/s")
