@@ -85,6 +85,10 @@ struct isingmc_states {
     uint2 *d_keys = nullptr;
     uint64_t t = 0; // absolute timestep = Philox counter
     hipStream_t stream = nullptr;
+    std::vector<hipStream_t> lanes; // sweep launches of disjoint replica blocks alternate over these (see run_steps)
+    std::vector<hipEvent_t> lane_events;
+    hipEvent_t fork_event = nullptr;
+    size_t n_lanes = 1; // lanes in use by the current run_steps call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool has_betas = false;
     std::vector<double> betas;
@@ -103,6 +107,9 @@ struct isingmc_states {
         for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
+        for (auto st : lanes) (void)hipStreamDestroy(st);
+        for (auto ev : lane_events) (void)hipEventDestroy(ev);
+        if (fork_event) (void)hipEventDestroy(fork_event);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -626,16 +633,51 @@ template <bool VEC, bool PMJ>
 static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &thr)
 {
     const isingmc_graph *g = s->g;
-    for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
-        const size_t n = std::min(MAX_GRID_Y, s->R - r0);
-        const auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream,
-                               s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
-                               s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
-        };
-        if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
-        else launch(lat_sweep_kernel<VEC, PMJ, false>);
+    // replicas are independent: with n_lanes > 1 the replica blocks go to different streams, so that the
+    // launch gap / ramp / tail of one block's half-sweep overlaps the other blocks' work
+    const size_t per_lane = (s->R + s->n_lanes - 1) / s->n_lanes;
+    for (size_t lane = 0; lane < s->n_lanes; lane++) {
+        const size_t lo = lane * per_lane, hi = std::min(s->R, lo + per_lane);
+        hipStream_t stream = s->n_lanes > 1 ? s->lanes[lane] : s->stream;
+        for (size_t r0 = lo; r0 < hi; r0 += MAX_GRID_Y) {
+            const size_t n = std::min(MAX_GRID_Y, hi - r0);
+            const auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, stream,
+                                   s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                                   s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
+            };
+            if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
+            else launch(lat_sweep_kernel<VEC, PMJ, false>);
+        }
     }
+}
+
+// fork: the lanes wait for everything queued on the main stream; join: the main stream waits for the lanes
+static int lanes_fork(isingmc_states *s, size_t n)
+{
+    while (s->lanes.size() < n) {
+        hipStream_t st;
+        hipEvent_t ev;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s->lanes.push_back(st);
+        s->lane_events.push_back(ev);
+    }
+    if (!s->fork_event) HIP_TRY(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->fork_event, s->stream));
+    for (size_t i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(s->lanes[i], s->fork_event, 0));
+    s->n_lanes = n;
+    return ISINGMC_OK;
+}
+
+static int lanes_join(isingmc_states *s)
+{
+    for (size_t i = 0; i < s->n_lanes && s->n_lanes > 1; i++) {
+        HIP_TRY(hipEventRecord(s->lane_events[i], s->lanes[i]));
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->lane_events[i], 0));
+    }
+    s->n_lanes = 1;
+    return ISINGMC_OK;
 }
 
 template <bool VEC, bool PMJ>
@@ -765,7 +807,9 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // per-step energies on the lattice path: integer counters per (step, replica), converted at the
     // end of each chunk; on the general path one measure() per step.
     // small lattices: one LDS-resident launch per chunk of timesteps instead of two launches per timestep
-    const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && !resident_disabled();
+    // (up to 1024 quads per colour: beyond that one workgroup per replica is slower than the launches it saves)
+    const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
+                          !resident_disabled();
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
     const bool gen_resident = !lattice && g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && !resident_disabled();
     if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
@@ -785,6 +829,17 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     if (resident && !s->has_betas) TRY(dev_alloc(&d_thr_steps, beta_stride ? chunk : 1));
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
+    // replica blocks on several streams.  Large launches (c2) keep the chip full on one stream.
+    size_t want_lanes = 1;
+    if (lattice && !resident && !energies_per_step) {
+        const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
+        const char *e = std::getenv("ISINGMC_STREAMS");
+        if (e) want_lanes = std::max(1, std::atoi(e));
+        else if (waves_per_launch < 64 * 1024) want_lanes = 2; // < 64 waves per SIMD per launch (measured: +17..33 %; 4 lanes go host-bound)
+        want_lanes = std::min(want_lanes, R);
+    }
+    if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
         if (d_steps) HIP_TRY(hipMemsetAsync(d_steps, 0, nk * R * 2 * sizeof(unsigned long long), s->stream));
@@ -857,6 +912,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                     energies_per_step[r * timesteps + k0 + k] = g->jabs * double(nbonds - 2 * int64_t(h_steps[(k * R + r) * 2]));
         }
     }
+    if (s->n_lanes > 1) { const int jrc = lanes_join(s); if (rc == ISINGMC_OK) rc = jrc; }
     if (device_ms && rc == ISINGMC_OK) {
         hipError_t err = hipEventRecord(s->ev1, s->stream);
         if (err == hipSuccess) err = hipEventSynchronize(s->ev1);
