@@ -154,6 +154,31 @@ int isingmc_get_packed_states(isingmc_states *states, uint32_t *words_out);
 /* Absolute timestep counter of the replicas (Philox counter word; persists across calls). */
 uint64_t isingmc_states_timestep(const isingmc_states *states);
 
+/* ---- on-stream parallel tempering (lattice path) --------------------------------------------------
+ * The classical counterpart of the loop in tempering.rs:177-194 { timesteps; parallel_tempering_step }
+ * with NO host synchronisation inside it: sweeps, the energy measurement, the exchange decisions
+ * (same arithmetic as isingmc_host_pt_swap_round) and the relabelling of the slots' betas are all
+ * enqueued on the engine's HIP stream.  Between isingmc_pt_measure and isingmc_pt_swap a multi-GPU
+ * caller all-gathers the `local` buffer of every rank into the `all` buffer ON THAT STREAM (RCCL:
+ * ncclAllGather / torch.distributed.all_gather_into_tensor under torch.cuda.ExternalStream); with a
+ * single rank isingmc_pt_measure fills `all` itself.
+ *
+ * attach: ladder_betas[n_rungs] in ladder order; this shard owns slots
+ * [slot_offset, slot_offset + n_replicas) of n_rungs, every rank owning slots_per_rank slots (the last
+ * ranks fewer); rung i starts on slot i; `seed` keys the exchange decisions. */
+int isingmc_pt_attach(isingmc_states *states, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
+                      size_t slots_per_rank, size_t world_size, uint64_t seed);
+/* device pointers: local = double[slots_per_rank] (send buffer), all = double[world_size*slots_per_rank] */
+int isingmc_pt_buffers(isingmc_states *states, void **d_local_out, void **d_all_out, size_t *per_rank_out);
+int isingmc_pt_time_steps(isingmc_states *states, size_t timesteps); /* enqueue only */
+int isingmc_pt_measure(isingmc_states *states);                      /* enqueue only */
+int isingmc_pt_swap(isingmc_states *states);                         /* enqueue only */
+/* synchronises; perm_out = uint32[n_rungs] (rung -> slot), exchange rounds done, accepted swaps */
+int isingmc_pt_state(isingmc_states *states, uint32_t *perm_out, uint64_t *round_out, uint64_t *swaps_out);
+/* the engine's hipStream_t (for enqueuing the collective) and a host-side wait for it */
+int isingmc_states_stream(isingmc_states *states, void **stream_out);
+int isingmc_synchronize(isingmc_states *states);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ __all__ = ["_capi", "load_extension"]
 
 def load_extension():
     """Import the C++ host shim; raises with a build hint when it has not been built."""
+    _capi.preload_hip_runtime()  # before the extension pulls in libisingmc.so -> libamdhip64
     try:
         from . import _py_monte_carlo
     except ImportError as exc:  # pragma: no cover - build problem

@@ -48,15 +48,46 @@ _PROTOTYPES = {
     "isingmc_get_states": (C.c_int, [_vp, _vp, C.c_size_t]),
     "isingmc_get_packed_states": (C.c_int, [_vp, _vp]),
     "isingmc_states_timestep": (C.c_uint64, [_vp]),
+    "isingmc_pt_attach": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64]),
+    "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "isingmc_pt_time_steps": (C.c_int, [_vp, C.c_size_t]),
+    "isingmc_pt_measure": (C.c_int, [_vp]),
+    "isingmc_pt_swap": (C.c_int, [_vp]),
+    "isingmc_pt_state": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "isingmc_states_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "isingmc_synchronize": (C.c_int, [_vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 
 _lib = None
+_hip_preloaded = False
+
+
+def preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy a
+    process loads first serves both torch and libisingmc.so; if the system copy wins, torch's other bundled
+    ROCm libraries no longer match it and torch.cuda reports no GPU.  So when torch is installed its copy
+    is loaded first (without importing torch); libisingmc.so then binds to that one."""
+    global _hip_preloaded
+    if _hip_preloaded:
+        return
+    _hip_preloaded = True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover - torch absent or laid out differently: use the system runtime
+        pass
 
 
 def lib():
     global _lib
     if _lib is None:
+        preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m pyisingmontecarlo_amd.build` "
@@ -250,6 +281,53 @@ class States:
         out = np.zeros((self.count, self.graph.state_words), dtype=np.uint32)
         _check(lib().isingmc_get_packed_states(self._h, _p(out)))
         return out
+
+    # ---- on-stream parallel tempering (lattice path): every call below only ENQUEUES on the engine's stream
+    def pt_attach(self, ladder_betas, slot_offset, slots_per_rank, world_size, seed):
+        b = _arr(ladder_betas, np.float64)
+        _check(lib().isingmc_pt_attach(self._h, _p(b), len(b), slot_offset, slots_per_rank, world_size,
+                                       C.c_uint64(int(seed))))
+        self._pt_rungs = len(b)
+        self._pt_world = world_size
+
+    def pt_buffers(self):
+        """(local, all) as torch CUDA tensors viewing the engine's device buffers (no copy)."""
+        import torch
+        loc, al, per = _vp(), _vp(), C.c_size_t()
+        _check(lib().isingmc_pt_buffers(self._h, C.byref(loc), C.byref(al), C.byref(per)))
+
+        class _View:  # __cuda_array_interface__ view of a raw device pointer
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        dev = torch.device("cuda", self.graph.info.device)
+        world = self._pt_world
+        return (torch.as_tensor(_View(loc.value, per.value), device=dev),
+                torch.as_tensor(_View(al.value, per.value * world), device=dev))
+
+    def pt_stream(self):
+        import torch
+        st = _vp()
+        _check(lib().isingmc_states_stream(self._h, C.byref(st)))
+        return torch.cuda.ExternalStream(st.value, device=torch.device("cuda", self.graph.info.device))
+
+    def pt_time_steps(self, timesteps):
+        _check(lib().isingmc_pt_time_steps(self._h, timesteps))
+
+    def pt_measure(self):
+        _check(lib().isingmc_pt_measure(self._h))
+
+    def pt_swap(self):
+        _check(lib().isingmc_pt_swap(self._h))
+
+    def pt_state(self):
+        perm = np.zeros(self._pt_rungs, dtype=np.uint32)
+        rnd, swaps = C.c_uint64(), C.c_uint64()
+        _check(lib().isingmc_pt_state(self._h, _p(perm), C.byref(rnd), C.byref(swaps)))
+        return perm, rnd.value, swaps.value
+
+    def synchronize(self):
+        _check(lib().isingmc_synchronize(self._h))
 
     def close(self):
         if self._h:

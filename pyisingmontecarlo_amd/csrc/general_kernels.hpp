@@ -284,4 +284,58 @@ __global__ __launch_bounds__(1024) void gen_resident_kernel(
     for (uint32_t i = tid; i < G.n_words; i += nthreads) mine[i] = st[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Parallel-tempering exchange round ON THE STREAM (host twin: pt_swap_round in
+// host_logic.cpp -- same Philox counters, same det_exp, hence the same decisions).  One workgroup:
+// the pairs (i, i+1) of the round's parity are disjoint, so one thread per pair swaps perm entries in
+// place; then every rung relabels its slot's beta / thresholds if the slot is local.  No host sync.
+// ------------------------------------------------------------------------------------------------
+struct PtDev {
+    const double *ladder;        // beta per rung
+    const uint64_t *ladder_thr;  // lattice: {T3, T4} per rung (host-computed, exp of glibc), else nullptr
+    uint32_t *perm;              // rung -> global slot
+    const double *slot_energy;   // all slots (gathered)
+    unsigned long long *counters; // [0] = round, [1] = total swaps
+    uint32_t n_rungs, slot_offset, n_local;
+    uint32_t seed_lo, seed_hi;
+};
+
+__global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *__restrict__ thr_local /*{T3,T4} per local slot*/,
+                                                       double *__restrict__ beta_local, const uint32_t apply_only)
+{
+    const unsigned long long round = P.counters[0];
+    __syncthreads(); // everyone has read the round before thread 0 bumps it
+    unsigned swaps = 0;
+    for (uint32_t i = uint32_t(round & 1) + 2 * threadIdx.x; !apply_only && i + 1 < P.n_rungs; i += 2 * blockDim.x) {
+        const uint32_t sa = P.perm[i], sb = P.perm[i + 1];
+        const double d = (P.ladder[i] - P.ladder[i + 1]) * (P.slot_energy[sa] - P.slot_energy[sb]);
+        bool accept = d >= 0.0;
+        if (!accept) {
+            const uint4 rnd = philox4x32_10(make_uint4(i, uint32_t(round), uint32_t(round >> 32), 0x50545357u),
+                                            make_uint2(P.seed_lo, P.seed_hi));
+            const uint64_t x = (uint64_t(rnd.y) << 32) | rnd.x;
+            accept = double(x >> 11) * (1.0 / 9007199254740992.0) < det_exp(d);
+        }
+        if (accept) {
+            P.perm[i] = sb;
+            P.perm[i + 1] = sa;
+            swaps++;
+        }
+    }
+    if (swaps) atomicAdd(&P.counters[1], (unsigned long long)swaps);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P.n_rungs; i += blockDim.x) {
+        const uint32_t slot = P.perm[i];
+        if (slot >= P.slot_offset && slot < P.slot_offset + P.n_local) {
+            const uint32_t r = slot - P.slot_offset;
+            beta_local[r] = P.ladder[i];
+            if (P.ladder_thr) {
+                thr_local[2 * size_t(r)] = P.ladder_thr[2 * size_t(i)];
+                thr_local[2 * size_t(r) + 1] = P.ladder_thr[2 * size_t(i) + 1];
+            }
+        }
+    }
+    if (threadIdx.x == 0 && !apply_only) P.counters[0] = round + 1;
+}
+
 } // namespace isingmc

@@ -99,6 +99,14 @@ struct isingmc_states {
     double *d_pe = nullptr, *d_oe = nullptr;
     long long *d_pm = nullptr, *d_om = nullptr;
     uint32_t n_partials = 0;
+    // on-stream parallel tempering (isingmc_pt_*)
+    bool pt_attached = false;
+    PtDev pt{};
+    double *d_pt_ladder = nullptr, *d_pt_local = nullptr, *d_pt_all = nullptr;
+    uint64_t *d_pt_ladder_thr = nullptr;
+    uint32_t *d_pt_perm = nullptr;
+    unsigned long long *d_pt_counters = nullptr;
+    size_t pt_per = 0, pt_world = 1;
 
     ~isingmc_states()
     {
@@ -106,6 +114,9 @@ struct isingmc_states {
         (void)hipSetDevice(g->device);
         for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
+            if (p) (void)hipFree(p);
+        for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
+                        (void *)d_pt_counters})
             if (p) (void)hipFree(p);
         for (auto st : lanes) (void)hipStreamDestroy(st);
         for (auto ev : lane_events) (void)hipEventDestroy(ev);
@@ -147,6 +158,9 @@ static int use_device(int device)
         return fail(ISINGMC_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range (" +
                                                std::to_string(count) + " devices)");
     HIP_TRY(hipSetDevice(device));
+    // the "last error" is per thread and shared with every other HIP user in the process (e.g. torch):
+    // clear what others left behind so that the hipGetLastError() checks after our launches see only ours
+    (void)hipGetLastError();
     return ISINGMC_OK;
 }
 
@@ -630,7 +644,7 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
 // sweeps
 // ------------------------------------------------------------------------------------------------
 template <bool VEC, bool PMJ>
-static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &thr)
+static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &thr, uint64_t t_arg)
 {
     const isingmc_graph *g = s->g;
     // replicas are independent: with n_lanes > 1 the replica blocks go to different streams, so that the
@@ -643,7 +657,7 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
             const size_t n = std::min(MAX_GRID_Y, hi - r0);
             const auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, stream,
-                                   s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                                   s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
                                    s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
             };
             if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
@@ -653,7 +667,7 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
 }
 
 // fork: the lanes wait for everything queued on the main stream; join: the main stream waits for the lanes
-static int lanes_fork(isingmc_states *s, size_t n)
+static int lanes_reserve(isingmc_states *s, size_t n)
 {
     while (s->lanes.size() < n) {
         hipStream_t st;
@@ -664,6 +678,12 @@ static int lanes_fork(isingmc_states *s, size_t n)
         s->lane_events.push_back(ev);
     }
     if (!s->fork_event) HIP_TRY(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+    return ISINGMC_OK;
+}
+
+static int lanes_fork(isingmc_states *s, size_t n)
+{
+    TRY(lanes_reserve(s, n));
     HIP_TRY(hipEventRecord(s->fork_event, s->stream));
     for (size_t i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(s->lanes[i], s->fork_event, 0));
     s->n_lanes = n;
@@ -789,7 +809,7 @@ static bool resident_disabled()
 }
 
 static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
-                     double *energies_per_step, float *device_ms)
+                     double *energies_per_step, float *device_ms, bool sync = true)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (timesteps && !betas && !s->has_betas) return fail(ISINGMC_ERR_INVALID, "betas is NULL");
@@ -836,7 +856,8 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
-        else if (waves_per_launch < 64 * 1024) want_lanes = 2; // < 64 waves per SIMD per launch (measured: +17..33 %; 4 lanes go host-bound)
+        // < 64 waves per SIMD per launch: +17..33 % with 2 lanes (4 go host-bound); short calls lose it to fork/join
+        else if (waves_per_launch < 64 * 1024 && timesteps >= 64) want_lanes = 2;
         want_lanes = std::min(want_lanes, R);
     }
     if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
@@ -888,8 +909,8 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
             if (lattice) {
                 const LatThr thr = lattice_thresholds(beta, g->jabs);
-                LAT_DISPATCH(launch_lat_sweep, s, 0u, thr);
-                LAT_DISPATCH(launch_lat_sweep, s, 1u, thr);
+                LAT_DISPATCH(launch_lat_sweep, s, 0u, thr, s->t);
+                LAT_DISPATCH(launch_lat_sweep, s, 1u, thr, s->t);
                 if (d_steps) LAT_DISPATCH(launch_lat_measure, s, d_steps + (k - k0) * R * 2, size_t(2));
             } else {
                 launch_gen_timestep(s, beta);
@@ -925,7 +946,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         if (p) (void)hipFree(p);
     if (rc != ISINGMC_OK) return rc;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (sync) HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
 }
 
@@ -984,5 +1005,134 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
             unpack_state(g, words.data() + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes);
         });
     }
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-stream parallel tempering (no host synchronisation inside the sweep / measure / swap loop)
+// ------------------------------------------------------------------------------------------------
+extern "C" int isingmc_states_stream(isingmc_states *s, void **stream_out)
+{
+    if (!s || !stream_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    *stream_out = s->stream;
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_synchronize(isingmc_states *s)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    TRY(use_device(s->g->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
+                                 size_t slots_per_rank, size_t world_size, uint64_t seed)
+{
+    if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
+    if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
+        return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
+    for (size_t i = 0; i < n_rungs; i++)
+        if (!std::isfinite(ladder_betas[i])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    const bool lattice = g->kind == ISINGMC_KIND_LATTICE2D;
+    TRY(dev_alloc(&s->d_pt_ladder, n_rungs));
+    TRY(dev_alloc(&s->d_pt_perm, n_rungs));
+    TRY(dev_alloc(&s->d_pt_local, slots_per_rank));
+    TRY(dev_alloc(&s->d_pt_all, slots_per_rank * world_size));
+    TRY(dev_alloc(&s->d_pt_counters, 2));
+    std::vector<uint32_t> perm(n_rungs);
+    for (size_t i = 0; i < n_rungs; i++) perm[i] = uint32_t(i);
+    HIP_TRY(hipMemcpy(s->d_pt_ladder, ladder_betas, n_rungs * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_pt_perm, perm.data(), n_rungs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_pt_counters, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->d_pt_local, 0, slots_per_rank * sizeof(double)));
+    HIP_TRY(hipMemset(s->d_pt_all, 0, slots_per_rank * world_size * sizeof(double)));
+    if (lattice) { // thresholds per rung from the host's exp: bit-identical to isingmc_states_set_betas
+        std::vector<uint64_t> thr(2 * n_rungs);
+        for (size_t i = 0; i < n_rungs; i++) {
+            const LatThr t = lattice_thresholds(ladder_betas[i], g->jabs);
+            thr[2 * i] = t.T3;
+            thr[2 * i + 1] = t.T4;
+        }
+        TRY(dev_alloc(&s->d_pt_ladder_thr, 2 * n_rungs));
+        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
+                  uint32_t(slot_offset), uint32_t(s->R), uint32_t(seed), uint32_t(seed >> 32)};
+    s->pt_per = slots_per_rank;
+    s->pt_world = world_size;
+    s->betas.assign(s->R, 0.0);
+    s->has_betas = true;
+    s->pt_attached = true;
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, reinterpret_cast<uint64_t *>(s->d_thr),
+                       s->d_beta, 1u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_pt_buffers(isingmc_states *s, void **d_local_out, void **d_all_out, size_t *per_rank_out)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    if (d_local_out) *d_local_out = s->d_pt_local;
+    if (d_all_out) *d_all_out = s->d_pt_all;
+    if (per_rank_out) *per_rank_out = s->pt_per;
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_pt_time_steps(isingmc_states *s, size_t timesteps)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false);
+}
+
+// enqueue: energies of the local slots -> the local send buffer (and straight into the gathered
+// buffer when there is a single rank)
+extern "C" int isingmc_pt_measure(isingmc_states *s)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    if (R == 0) return ISINGMC_OK;
+    if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
+        hipLaunchKernelGGL(lat_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas,
+                           uint32_t(R), g->jabs, 2ll * (long long)g->nvars, s->d_pt_local);
+    } else {
+        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path; use the host swap step");
+    }
+    if (s->pt_world == 1)
+        HIP_TRY(hipMemcpyAsync(s->d_pt_all + s->pt.slot_offset, s->d_pt_local, R * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipGetLastError());
+    return ISINGMC_OK;
+}
+
+// enqueue: one exchange round from the gathered energies; relabels the local slots
+extern "C" int isingmc_pt_swap(isingmc_states *s)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    TRY(use_device(s->g->device));
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, reinterpret_cast<uint64_t *>(s->d_thr),
+                       s->d_beta, 0u);
+    HIP_TRY(hipGetLastError());
+    return ISINGMC_OK;
+}
+
+// synchronises; perm_out: uint32[n_rungs] (rung -> slot)
+extern "C" int isingmc_pt_state(isingmc_states *s, uint32_t *perm_out, uint64_t *round_out, uint64_t *swaps_out)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    TRY(use_device(s->g->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (perm_out) HIP_TRY(hipMemcpy(perm_out, s->d_pt_perm, s->pt.n_rungs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (round_out) *round_out = c[0];
+    if (swaps_out) *swaps_out = c[1];
     return ISINGMC_OK;
 }

@@ -386,4 +386,12 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
         reinterpret_cast<uint4 *>(mine)[i] = reinterpret_cast<const uint4 *>(planes)[i];
 }
 
+// lattice energies from the satisfied-bond counters: E = |J| (n_bonds - 2 sat)  (exact in f64)
+__global__ void lat_energy_from_counts_kernel(const unsigned long long *__restrict__ meas, const uint32_t n,
+                                              const double jabs, const long long n_bonds, double *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = jabs * double(n_bonds - 2 * (long long)meas[2 * size_t(r)]);
+}
+
 } // namespace isingmc

@@ -21,6 +21,8 @@ class HipEngine:
     def __init__(self, ea, eb, ej, nvars, device=0):
         self.graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=device)
         self.nvars = self.graph.nvars
+        # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream
+        self.supports_on_stream_pt = self.graph.kind == _capi.KIND_LATTICE2D
 
     def make_states(self, seeds):
         return _capi.States(self.graph, seeds)
@@ -62,6 +64,7 @@ class ClassicalTempering:
         self._perm = None       # rung -> slot
         self._round = 0
         self._total_swaps = 0
+        self._on_stream = False
 
     def _default_device(self):
         import os
@@ -87,6 +90,8 @@ class ClassicalTempering:
         return len(self._betas)
 
     def get_total_swaps(self):  # tempering.rs:297-299
+        if self._on_stream:
+            return int(self._states.pt_state()[2]) if self._hi > self._lo else self._total_swaps
         return self._total_swaps
 
     def get_betas(self):
@@ -95,6 +100,8 @@ class ClassicalTempering:
     def get_permutation(self):
         """rung -> replica slot currently holding that temperature."""
         self._materialise()
+        if self._on_stream and self._hi > self._lo:
+            self._perm = self._states.pt_state()[0]
         return self._perm.copy()
 
     # -------------------------------------------------------------------------------------------
@@ -109,7 +116,16 @@ class ClassicalTempering:
         self._engine = self._engine_factory()
         self._states = self._engine.make_states(np.array(self._slot_seeds[self._lo:self._hi], dtype=np.uint64))
         self._perm = np.arange(G, dtype=np.uint32)
-        self._push_betas()
+        self._on_stream = bool(getattr(self._engine, "supports_on_stream_pt", False)) and self._hi > self._lo
+        if self._world > 1:  # every rank must take the same path (the collective differs)
+            flags = D.all_gather_f64(np.array([float(self._on_stream)]), 1, self._group)
+            self._on_stream = bool(flags.min() > 0)
+        if self._on_stream:
+            self._states.pt_attach(self._betas, self._lo, self._per, self._world, self._seed)
+            self._pt_local, self._pt_all = self._states.pt_buffers()
+            self._pt_stream = self._states.pt_stream() if self._world > 1 else None
+        else:
+            self._push_betas()
 
     def _push_betas(self):
         G = len(self._betas)
@@ -128,18 +144,48 @@ class ClassicalTempering:
             out[lo:hi] = gathered[r * self._per:r * self._per + (hi - lo)]
         return out
 
-    def _swap_step(self):
+    def _swap_step(self, need_perm=False):
+        if self._on_stream:
+            # measure -> [RCCL all-gather on the engine's stream] -> exchange kernel: nothing waits on the host
+            self._states.pt_measure()
+            if self._world > 1:
+                import torch
+                import torch.distributed as dist
+                with torch.cuda.stream(self._pt_stream):
+                    dist.all_gather_into_tensor(self._pt_all, self._pt_local, group=self._group)
+            self._states.pt_swap()
+            if need_perm:
+                self._perm = self._states.pt_state()[0]
+            return
         local = self._states.energies() if self._hi > self._lo else np.zeros(0)
         slot_e = self._slot_energies(local)
         self._total_swaps += _capi.pt_swap_round(self._seed, self._round, self._betas, slot_e, self._perm)
         self._round += 1
         self._push_betas()
 
-    def timesteps(self, t):
-        """tempering.rs:150-152 (parallel_timesteps): t sweeps on every rung, no swaps."""
+    def timesteps(self, t, replica_swap_freq=None):
+        """tempering.rs:150-152 (parallel_timesteps): t sweeps on every rung.  replica_swap_freq (extension):
+        an exchange round after every `replica_swap_freq` sweeps, as in the loop of tempering.rs:177-194."""
         self._materialise()
-        if self._hi > self._lo and t > 0:
-            self._states.do_time_steps(t)
+        if t <= 0:
+            return
+        if not replica_swap_freq:
+            if self._hi > self._lo:
+                self._states.do_time_steps(t)
+            return
+        done = 0
+        while done < t:
+            b = min(int(replica_swap_freq), t - done)
+            if self._hi > self._lo:
+                if self._on_stream:
+                    self._states.pt_time_steps(b)
+                else:
+                    self._states.do_time_steps(b)
+            done += b
+            if b == replica_swap_freq:
+                self._swap_step()
+        if self._on_stream:
+            self._states.synchronize()
 
     def timesteps_sample(self, timesteps, replica_swap_freq=None, sampling_freq=None):
         """tempering.rs:156-222: countdown scheduler of run / swap / sample.
@@ -150,6 +196,8 @@ class ClassicalTempering:
         held at each sample (configurations never leave their GPU).
         """
         self._materialise()
+        if self._on_stream and self._hi > self._lo:
+            self._perm = self._states.pt_state()[0]  # the device owns the ladder state
         sampling_freq = 1 if sampling_freq is None else int(sampling_freq)
         replica_swap_freq = 1 if replica_swap_freq is None else int(replica_swap_freq)
         if sampling_freq <= 0:
@@ -173,7 +221,7 @@ class ClassicalTempering:
             to_swap -= t
             remaining -= t
             if to_swap == 0 and replica_swap_freq > 0:
-                self._swap_step()
+                self._swap_step(need_perm=True)
                 to_swap = replica_swap_freq
             if to_sample == 0:
                 if n_local and k < S:

@@ -269,3 +269,24 @@ def test_tempering_matches_oracle_engine(capi, exact):
     assert np.array_equal(runs[0][1], runs[1][1])
     assert np.array_equal(runs[0][0], runs[1][0])
     assert runs[0][0].shape == (7, 4, W * H)
+
+
+def test_on_stream_tempering_equals_host_swap_path(capi, exact):
+    """timesteps(t, replica_swap_freq) keeps sweeps, measurement, exchange decisions and relabelling on the
+    HIP stream; it must reproduce the host-side swap step (oracle engine) decision for decision."""
+    from helpers import OracleLatEngine
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    W, H = 64, 8
+    edges = exact.square_lattice_edges(W, H, -1.0)
+    runs = []
+    for factory in (None, lambda: OracleLatEngine(W, H)):
+        pt = ClassicalTempering(edges, seed=11, engine_factory=factory)
+        for b in np.linspace(0.36, 0.52, 9):
+            pt.add_graph(b)
+        pt.timesteps(4)
+        pt.timesteps(33, replica_swap_freq=3)            # 11 exchange rounds
+        states, energies = pt.timesteps_sample(6, replica_swap_freq=2, sampling_freq=3)
+        runs.append((pt.get_permutation(), pt.get_total_swaps(), states, energies))
+    assert runs[0][1] == runs[1][1] > 0
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)

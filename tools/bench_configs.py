@@ -57,9 +57,7 @@ def c3(steps):
     pt.timesteps(20)
     t0 = time.perf_counter()
     n_blocks = steps // 10
-    for _ in range(n_blocks):
-        pt.timesteps(10)
-        pt._swap_step()
+    pt.timesteps(n_blocks * 10, replica_swap_freq=10)   # sweeps + exchange rounds, all on the engine's stream
     dt = time.perf_counter() - t0
     return {"config": "c3", "lattice": [L, L], "rungs": G, "steps": n_blocks * 10, "swap_every": 10,
             "attempts_per_s": G * L * L * n_blocks * 10 / dt, "ms_per_step": dt * 1e3 / (n_blocks * 10),
