@@ -72,6 +72,8 @@ def preload_hip_runtime():
     if _hip_preloaded:
         return
     _hip_preloaded = True
+    if os.environ.get("ISINGMC_NO_TORCH_HIP_PRELOAD"):  # diagnostics: run on the system ROCm runtime
+        return
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")

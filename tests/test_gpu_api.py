@@ -290,3 +290,44 @@ def test_on_stream_tempering_equals_host_swap_path(capi, exact):
     assert runs[0][1] == runs[1][1] > 0
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)
+
+
+def test_on_stream_tempering_two_shards_in_one_process(capi, exact):
+    """The multi-GPU exchange protocol with both 'ranks' on this one GPU: two shard engines attach halves of
+    the ladder; the all-gather between pt_measure and pt_swap is emulated by device copies issued on each
+    engine's own stream (torch.cuda.ExternalStream, the object the RCCL collective is enqueued under).
+    Result must equal the unsharded ladder: same permutation, swaps and configurations."""
+    import torch
+    W, H, G = 64, 8, 8
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(3, G)
+    betas = np.linspace(0.38, 0.5, G)
+    full = capi.States(g, seeds)
+    full.pt_attach(betas, 0, G, 1, 99)
+    shards = [capi.States(g, seeds[:4]), capi.States(g, seeds[4:])]
+    for k, sh in enumerate(shards):
+        sh.pt_attach(betas, 4 * k, 4, 2, 99)
+    bufs = [sh.pt_buffers() for sh in shards]
+    streams = [sh.pt_stream() for sh in shards]
+    assert bufs[0][0].shape == (4,) and bufs[0][1].shape == (8,) and bufs[0][1].dtype == torch.float64
+    for rnd in range(12):
+        full.pt_time_steps(2); full.pt_measure(); full.pt_swap()
+        for sh in shards:
+            sh.pt_time_steps(2)
+            sh.pt_measure()
+        for sh in shards:
+            sh.synchronize()
+        for k in range(2):                                  # "all-gather": rank-major concatenation of the locals
+            with torch.cuda.stream(streams[k]):
+                bufs[k][1][:4].copy_(bufs[0][0])
+                bufs[k][1][4:].copy_(bufs[1][0])
+        for sh in shards:
+            sh.pt_swap()
+    perm, rounds, swaps = full.pt_state()
+    assert rounds == 12 and swaps > 0
+    for sh in shards:
+        p, r, s = sh.pt_state()
+        assert np.array_equal(p, perm) and r == rounds
+    assert shards[0].pt_state()[2] == swaps                 # every rank counts the same accepted swaps
+    assert np.array_equal(np.concatenate([sh.packed() for sh in shards]), full.packed())
