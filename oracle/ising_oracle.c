@@ -665,3 +665,100 @@ uint64_t orc_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const 
     }
     return swaps;
 }
+
+/* ==========================================================================================
+ * D. replica-packed general engine: graphs with one |J|, no fields, degree <= 6.
+ * Same colouring and positions as engine C; replicas live in groups of 32 that share Philox calls
+ * (replica 32g+b takes bit b of every random word of group g, whose key is the seed of replica 32g).
+ * A spin with k satisfied bonds out of deg flips always when m = 2k - deg <= 0, else iff
+ * u < T_m = fixed(exp(-beta 2|J| m)), u built exactly as in S3: N_PLANES prefix bits from the
+ * position-quad's plane words, 32 more bits for ties, which are numbered over the whole
+ * position-quad in (position, replica bit) order -- over all 32 bits, so the unused replicas of a
+ * last, partial group are simulated too (they take tie words).
+ * states: uint8[32*G][nvars], G = ceil(R/32); replicas >= R are the padding of the last group.
+ * betas: per timestep (beta_replica == NULL) or beta_replica[R] (then padding replicas use
+ * beta_replica[R-1]).
+ * ======================================================================================== */
+#define DOM_PK_SWEEP 0x504B5357u
+#define DOM_PK_INIT 0x504B494Eu
+
+void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                size_t nvars, const uint64_t *seeds, size_t R, int random_start, uint64_t t0,
+                const double *betas, const double *beta_replica, size_t timesteps,
+                uint8_t *states, double *energies_out, double *energies_per_step)
+{
+    gen_graph G;
+    gen_build(&G, n_edges, ea, eb, ej, nvars);
+    double jabs = 0.0;
+    for (size_t k = 0; k < n_edges; k++)
+        if (ea[k] != eb[k]) { jabs = fabs(ej[k]); break; }
+    size_t groups = (R + 31) / 32;
+    /* site of each position (SIZE_MAX on padding) */
+    size_t *site_of = malloc(G.npos * sizeof(size_t));
+    for (size_t p = 0; p < G.npos; p++) site_of[p] = (size_t)-1;
+    for (size_t i = 0; i < nvars; i++) site_of[G.pos[i]] = i;
+
+    for (size_t g = 0; g < groups; g++) {
+        uint64_t key = seeds[32 * g];
+        uint8_t *S = states + 32 * g * nvars; /* S[b*nvars + i] */
+        if (random_start)
+            for (size_t i = 0; i < nvars; i++) {
+                size_t p = G.pos[i];
+                uint32_t r[4];
+                philox_seeded(key, 0, (uint32_t)(p >> 2), 0, DOM_PK_INIT, r);
+                for (int b = 0; b < 32; b++) S[(size_t)b * nvars + i] = (uint8_t)((r[p & 3] >> b) & 1u);
+            }
+        for (size_t k = 0; k < timesteps; k++) {
+            uint64_t t = t0 + k;
+            for (uint32_t c = 0; c < G.ncolours; c++)
+                for (size_t p0 = G.class_base[c]; p0 < G.class_base[c + 1]; p0 += 4) {
+                    uint32_t planes[N_PLANES][4], tie_words[4];
+                    unsigned n_ties = 0;
+                    for (uint32_t pl = 0; pl < N_PLANES; pl++)
+                        philox_seeded(key, (uint32_t)t, (uint32_t)(p0 >> 2), ctr2(t, 0, pl), DOM_PK_SWEEP, planes[pl]);
+                    for (int q = 0; q < 4; q++) {
+                        size_t i = site_of[p0 + q];
+                        if (i == (size_t)-1) continue;
+                        int deg = (int)(G.A.ptr[i + 1] - G.A.ptr[i]);
+                        for (int b = 0; b < 32; b++) {
+                            uint8_t *s = S + (size_t)b * nvars;
+                            size_t r = 32 * g + b;
+                            double beta = beta_replica ? beta_replica[r < R ? r : R - 1] : betas[k];
+                            int sat = 0;
+                            for (size_t e = G.A.ptr[i]; e < G.A.ptr[i + 1]; e++) {
+                                int differ = s[i] != s[G.A.nbr[e]];
+                                sat += (G.A.w[e] > 0.0) ? differ : !differ;
+                            }
+                            int m = 2 * sat - deg, accept;
+                            if (m <= 0) accept = 1;
+                            else {
+                                uint64_t T = orc_threshold_fixed(beta, 2.0 * jabs * (double)m);
+                                uint32_t hi = (uint32_t)(T >> 32), lo = (uint32_t)T, upre = 0;
+                                for (int pl = 0; pl < N_PLANES; pl++) upre = (upre << 1) | ((planes[pl][q] >> b) & 1u);
+                                if (upre < hi) accept = 1;
+                                else if (upre > hi) accept = 0;
+                                else {
+                                    if ((n_ties & 3) == 0)
+                                        philox_seeded(key, (uint32_t)t, (uint32_t)(p0 >> 2),
+                                                      ctr2(t, 0, N_PLANES + n_ties / 4), DOM_PK_SWEEP, tie_words);
+                                    accept = tie_words[n_ties & 3] < lo;
+                                    n_ties++;
+                                }
+                            }
+                            /* the sites of a colour class are independent: in place == simultaneous */
+                            if (accept) s[i] = !s[i];
+                        }
+                    }
+                }
+            if (energies_per_step)
+                for (int b = 0; b < 32 && 32 * g + b < R; b++)
+                    energies_per_step[(32 * g + b) * timesteps + k] =
+                        orc_energy(n_edges, ea, eb, ej, nvars, NULL, S + (size_t)b * nvars);
+        }
+        if (energies_out)
+            for (int b = 0; b < 32 && 32 * g + b < R; b++)
+                energies_out[32 * g + b] = orc_energy(n_edges, ea, eb, ej, nvars, NULL, S + (size_t)b * nvars);
+    }
+    free(site_of);
+    gen_free(&G);
+}

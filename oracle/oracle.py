@@ -62,6 +62,8 @@ def lib():
         L.orc_gen_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p,
                                   C.c_uint64, C.c_void_p, C.c_uint64, f64p, C.c_size_t, u8p,
                                   C.c_void_p, C.c_void_p]
+        L.orc_pk_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, u64p, C.c_size_t, C.c_int, C.c_uint64,
+                                 C.c_void_p, C.c_void_p, C.c_size_t, u8p, C.c_void_p, C.c_void_p]
         L.orc_pt_swap_round.restype = C.c_uint64
         L.orc_pt_swap_round.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, f64p, f64p, u32p]
         _LIB = L
@@ -200,3 +202,20 @@ def pt_swap_round(seed, rnd, betas, slot_energy, perm):
     slot_energy = np.ascontiguousarray(slot_energy, dtype=np.float64)
     return int(lib().orc_pt_swap_round(C.c_uint64(int(seed)), C.c_uint64(int(rnd)), len(betas),
                                        betas, slot_energy, perm))
+
+
+def pk_run(ea, eb, ej, nvars, seeds, timesteps, betas=None, beta_replica=None, states=None, t0=0, per_step=False):
+    """Replica-packed spec engine (engine D).  states: None (random start) or uint8[32*ceil(R/32), nvars]
+    carried over from a previous call.  Returns (energies[R], states[32G, nvars][, per-step energies])."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    R = len(seeds)
+    G = (R + 31) // 32
+    random_start = states is None
+    st = np.zeros((32 * G, nvars), dtype=np.uint8) if states is None else np.ascontiguousarray(states, dtype=np.uint8)
+    b = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+    br = None if beta_replica is None else np.ascontiguousarray(beta_replica, dtype=np.float64)
+    e = np.zeros(R, dtype=np.float64)
+    eps = np.zeros((R, timesteps), dtype=np.float64) if per_step else None
+    lib().orc_pk_run(len(ea), ea, eb, ej, nvars, seeds, R, int(random_start), C.c_uint64(int(t0)), _ptr(b), _ptr(br),
+                     timesteps, st, _ptr(e), _ptr(eps))
+    return (e, st, eps) if per_step else (e, st)

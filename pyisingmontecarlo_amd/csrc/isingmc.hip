@@ -18,6 +18,7 @@
 #include "general_kernels.hpp"
 #include "host_logic.hpp"
 #include "lattice_kernels.hpp"
+#include "packed_kernels.hpp"
 
 using namespace isingmc;
 
@@ -69,6 +70,10 @@ struct isingmc_graph {
     std::vector<uint64_t> pos; // site -> packed position
     double self_energy = 0.0;
     uint32_t n_colours = 2;
+    // replica-packed variant of the general path (uniform |J|, no fields, degree <= PK_MAX_DEG)
+    bool packed_ok = false;
+    PkGraphDev pk{};
+    uint64_t n_directed = 0;
     std::vector<void *> dev_allocs;
 
     ~isingmc_graph()
@@ -99,6 +104,10 @@ struct isingmc_states {
     double *d_pe = nullptr, *d_oe = nullptr;
     long long *d_pm = nullptr, *d_om = nullptr;
     uint32_t n_partials = 0;
+    // replica-packed general path: one word per position = 32 replicas of a group
+    bool packed = false;
+    size_t groups = 0;
+    uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
     // on-stream parallel tempering (isingmc_pt_*)
     bool pt_attached = false;
     PtDev pt{};
@@ -115,6 +124,7 @@ struct isingmc_states {
         for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
+        if (d_tab) (void)hipFree(d_tab);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
                         (void *)d_pt_counters})
             if (p) (void)hipFree(p);
@@ -430,6 +440,29 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
         TRY(graph_upload(g, &d, w));
         D.w = d;
     }
+    // replica-packed eligibility: one |J| for every bond, no fields, degree <= PK_MAX_DEG
+    {
+        uint64_t maxdeg = 0;
+        for (size_t i = 0; i < nvars; i++) maxdeg = std::max(maxdeg, A.ptr[i + 1] - A.ptr[i]);
+        bool uniform = !w.empty() && !g->has_bias && maxdeg <= PK_MAX_DEG && n_pos < 0x80000000u;
+        const double jabs = w.empty() ? 0.0 : std::fabs(w[0]);
+        for (double x : w) uniform &= std::fabs(x) == jabs;
+        uniform &= jabs > 0.0;
+        if (uniform) {
+            std::vector<uint32_t> nbr_sgn(nbr.size());
+            for (size_t e = 0; e < nbr.size(); e++) nbr_sgn[e] = nbr[e] | (w[e] > 0.0 ? 0x80000000u : 0u);
+            PkGraphDev &P = g->pk;
+            TRY(graph_upload(g, &P.nbr_sgn, nbr_sgn));
+            P.rowptr = D.rowptr;
+            P.site = D.site;
+            P.class_base = D.class_base;
+            P.n_colours = D.n_colours;
+            P.n_pos = n_pos;
+            g->packed_ok = true;
+            g->jabs = jabs;
+            g->n_directed = nbr.size();
+        }
+    }
     D.bias = nullptr;
     if (g->has_bias) {
         std::vector<double> bias(n_pos, 0.0);
@@ -497,6 +530,12 @@ static dim3 lat_grid(const isingmc_graph *g, uint32_t quads, size_t replicas)
 }
 
 constexpr size_t MAX_GRID_Y = 32768;
+
+// replica-packed general path (defined further down)
+static bool choose_packed(const isingmc_graph *g, size_t n_replicas);
+static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const uint8_t *initial_state);
+static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
+static int pk_set_betas(isingmc_states *s);
 
 // random start for replicas [first, first+count)
 static int init_random(isingmc_states *s, size_t first, size_t count)
@@ -588,8 +627,12 @@ extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const 
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
-    TRY(reserve(s.get(), std::max<size_t>(n_replicas, 1)));
-    TRY(add_replicas(s.get(), n_replicas, seeds, initial_state));
+    if (choose_packed(g, n_replicas)) {
+        TRY(pk_create(s.get(), n_replicas, seeds, initial_state));
+    } else {
+        TRY(reserve(s.get(), std::max<size_t>(n_replicas, 1)));
+        TRY(add_replicas(s.get(), n_replicas, seeds, initial_state));
+    }
     *states_out = s.release();
     return ISINGMC_OK;
 }
@@ -598,6 +641,7 @@ extern "C" int isingmc_states_append(isingmc_states *s, uint64_t seed, const uin
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (s->has_betas) return fail(ISINGMC_ERR_INVALID, "clear the per-replica betas before appending replicas");
+    if (s->packed) return fail(ISINGMC_ERR_INVALID, "replica-packed states cannot grow: create them with all experiments");
     TRY(use_device(s->g->device));
     return add_replicas(s, 1, &seed, initial_state);
 }
@@ -607,6 +651,7 @@ extern "C" int isingmc_states_set_state(isingmc_states *s, size_t replica, const
     if (!s || !state) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     if (replica >= s->R) return fail(ISINGMC_ERR_INVALID, "replica index out of range");
     TRY(use_device(s->g->device));
+    if (s->packed) return pk_set_state(s, replica, state);
     return upload_state(s, replica, 1, state);
 }
 
@@ -628,6 +673,11 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
         if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
     s->betas.assign(beta_per_replica, beta_per_replica + s->R);
+    if (s->packed) {
+        if (s->R) TRY(pk_set_betas(s));
+        s->has_betas = true;
+        return ISINGMC_OK;
+    }
     if (s->g->kind == ISINGMC_KIND_LATTICE2D) {
         std::vector<LatThr> thr(s->R);
         for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds(s->betas[r], s->g->jabs);
@@ -637,6 +687,210 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->has_betas = true;
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// replica-packed general path (packed_kernels.hpp): state = uint32[groups][n_pos], group g = replicas
+// 32g .. 32g+31, keyed by the seed of its first replica
+// ------------------------------------------------------------------------------------------------
+static bool env_flag(const char *name)
+{
+    const char *e = std::getenv(name);
+    return e && e[0] && e[0] != '0';
+}
+
+// worth it from 16 replicas on and when the graph is too big for the LDS-resident per-replica kernel
+static bool choose_packed(const isingmc_graph *g, size_t n_replicas)
+{
+    if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return false;
+    if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0;
+    return n_replicas >= 16 && g->state_words * sizeof(uint32_t) > GEN_RESIDENT_MAX_BYTES;
+}
+
+// threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)
+template <typename F>
+static void pk_fill_table(uint32_t *tab, double jabs, F &&beta_of)
+{
+    std::fill(tab, tab + PK_TAB_WORDS, 0u);
+    for (uint32_t m = 1; m <= uint32_t(PK_MAX_DEG); m++)
+        for (uint32_t r = 0; r < 32; r++) {
+            const uint64_t T = threshold_fixed(beta_of(r), 2.0 * jabs * double(m));
+            if (T >> THR_BITS) tab[PK_TAB_ALL + m - 1] |= 1u << r;
+            const uint32_t hi = uint32_t(T >> 32) & ((1u << N_PLANES) - 1);
+            for (int p = 0; p < N_PLANES; p++)
+                if ((hi >> (N_PLANES - 1 - p)) & 1u) tab[PK_TAB_TBW + (m - 1) * N_PLANES + p] |= 1u << r;
+            tab[PK_TAB_LO + (m - 1) * 32 + r] = uint32_t(T);
+        }
+}
+
+static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const uint8_t *initial_state)
+{
+    const isingmc_graph *g = s->g;
+    s->packed = true;
+    s->groups = (n + 31) / 32;
+    s->R = s->cap = n;
+    TRY(dev_alloc(&s->d_state, s->groups * g->pk.n_pos));
+    TRY(dev_alloc(&s->d_keys, s->groups));
+    TRY(dev_alloc(&s->d_meas, 2 * n));
+    std::vector<uint2> keys(s->groups);
+    for (size_t k = 0; k < s->groups; k++) keys[k] = make_uint2(uint32_t(seeds[32 * k]), uint32_t(seeds[32 * k] >> 32));
+    HIP_TRY(hipMemcpy(s->d_keys, keys.data(), keys.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    if (initial_state) { // every replica starts from the same configuration: a word is all ones or all zeros
+        std::vector<uint32_t> words(g->pk.n_pos, 0u);
+        for (uint64_t i = 0; i < g->nvars; i++) words[g->pos[i]] = initial_state[i] ? 0xFFFFFFFFu : 0u;
+        for (size_t k = 0; k < s->groups; k++)
+            HIP_TRY(hipMemcpy(s->d_state + k * g->pk.n_pos, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else {
+        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+            hipLaunchKernelGGL(pk_init_kernel, dim3((g->pk.n_pos + 255) / 256, unsigned(ng)), dim3(256), 0, s->stream, s->d_state,
+                               g->pk, s->d_keys, uint32_t(g0));
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return ISINGMC_OK;
+}
+
+static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins)
+{
+    const isingmc_graph *g = s->g;
+    std::vector<uint32_t> bits(g->state_words, 0u);
+    for (uint64_t i = 0; i < g->nvars; i++)
+        if (spins[i]) bits[g->pos[i] >> 5] |= 1u << (g->pos[i] & 31);
+    uint32_t *d_bits = nullptr;
+    TRY(dev_alloc(&d_bits, bits.size()));
+    hipError_t err = hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(pk_set_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state,
+                           g->pk.n_pos, d_bits, uint32_t(replica / 32), uint32_t(replica % 32));
+        err = hipStreamSynchronize(s->stream);
+    }
+    (void)hipFree(d_bits);
+    if (err != hipSuccess) return fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+    return ISINGMC_OK;
+}
+
+static int pk_set_betas(isingmc_states *s)
+{
+    std::vector<uint32_t> tabs(s->groups * PK_TAB_WORDS);
+    for (size_t k = 0; k < s->groups; k++)
+        pk_fill_table(tabs.data() + k * PK_TAB_WORDS, s->g->jabs,
+                      [&](uint32_t r) { return s->betas[std::min(s->R - 1, 32 * k + r)]; });
+    if (s->d_tab) HIP_TRY(hipFree(s->d_tab));
+    s->d_tab = nullptr;
+    TRY(dev_alloc(&s->d_tab, tabs.size()));
+    HIP_TRY(hipMemcpy(s->d_tab, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+
+static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride)
+{
+    const isingmc_graph *g = s->g;
+    for (uint32_t c = 0; c < g->n_colours; c++) {
+        const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
+        if (e == b) continue;
+        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+            hipLaunchKernelGGL(pk_sweep_kernel, dim3(((e - b) / 4 + 255) / 256, unsigned(ng)), dim3(256), 0, s->stream,
+                               s->d_state + g0 * g->pk.n_pos, g->pk, b, e, s->t, s->d_keys + g0,
+                               tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
+        }
+    }
+}
+
+static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
+{
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(1024, g->pk.n_pos / 2048)));
+    for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+        const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+        hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
+                           s->d_state + g0 * g->pk.n_pos, g->pk, s->d_meas + 2 * 32 * g0, uint32_t(R - 32 * g0));
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> h(2 * R);
+    HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (size_t r = 0; r < R; r++) { // E = |J| (undirected bonds - 2 satisfied) + self loops; directed counts are doubled
+        if (energies) energies[r] = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h[2 * r]))) + g->self_energy;
+        if (mags) mags[r] = 2 * int64_t(h[2 * r + 1]) - int64_t(g->nvars);
+    }
+    return ISINGMC_OK;
+}
+
+static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
+                        double *energies_per_step, float *device_ms, bool sync)
+{
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    uint32_t *d_step_tabs = nullptr;
+    const size_t chunk = std::min<size_t>(timesteps, 2048);
+    if (!s->has_betas) TRY(dev_alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
+    std::vector<uint32_t> h_tabs;
+    int rc = ISINGMC_OK;
+    if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
+        const size_t nk = std::min(chunk, timesteps - k0);
+        if (!s->has_betas && (beta_stride || k0 == 0)) {
+            h_tabs.resize((beta_stride ? nk : 1) * PK_TAB_WORDS);
+            for (size_t k = 0; k < h_tabs.size() / PK_TAB_WORDS; k++) {
+                const double beta = betas[(k0 + k) * beta_stride];
+                pk_fill_table(h_tabs.data() + k * PK_TAB_WORDS, g->jabs, [&](uint32_t) { return beta; });
+            }
+            HIP_TRY(hipMemcpy(d_step_tabs, h_tabs.data(), h_tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        for (size_t k = 0; k < nk && rc == ISINGMC_OK; k++) {
+            if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
+            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
+            s->t++;
+            if (energies_per_step) {
+                std::vector<double> e(R);
+                rc = pk_measure(s, e.data(), nullptr);
+                for (size_t r = 0; r < R && rc == ISINGMC_OK; r++) energies_per_step[r * timesteps + k0 + k] = e[r];
+            }
+        }
+        if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    if (device_ms && rc == ISINGMC_OK) {
+        hipError_t err = hipEventRecord(s->ev1, s->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(s->ev1);
+        if (err == hipSuccess) err = hipEventElapsedTime(device_ms, s->ev0, s->ev1);
+        if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+    }
+    if (rc == ISINGMC_OK) {
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess && (sync || d_step_tabs)) err = hipStreamSynchronize(s->stream);
+        if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+    }
+    if (d_step_tabs) (void)hipFree(d_step_tabs);
+    return rc;
+}
+
+// packed words -> one byte per spin, replica by replica
+static int pk_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes, uint32_t *packed_out)
+{
+    const isingmc_graph *g = s->g;
+    std::vector<uint32_t> words(s->groups * g->pk.n_pos);
+    HIP_TRY(hipMemcpyAsync(words.data(), s->d_state, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    parallel_for(s->R, [&](size_t r) {
+        const uint32_t *w = words.data() + (r / 32) * g->pk.n_pos;
+        const uint32_t bit = uint32_t(r % 32);
+        if (states_out) {
+            uint8_t *out = states_out + r * replica_stride_bytes;
+            for (uint64_t i = 0; i < g->nvars; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
+        }
+        if (packed_out) { // the per-replica layout of the thread-per-site path (bit-packed by position)
+            uint32_t *out = packed_out + r * g->state_words;
+            std::fill(out, out + g->state_words, 0u);
+            for (uint64_t i = 0; i < g->nvars; i++)
+                out[g->pos[i] >> 5] |= ((w[g->pos[i]] >> bit) & 1u) << (g->pos[i] & 31);
+        }
+    });
     return ISINGMC_OK;
 }
 
@@ -760,6 +1014,7 @@ static int measure(isingmc_states *s, double *energies, int64_t *mags)
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
     if (R == 0) return ISINGMC_OK;
+    if (s->packed) return pk_measure(s, energies, mags);
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
         HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
         LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
@@ -822,6 +1077,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     const size_t R = s->R;
     if (R == 0) s->t += timesteps; // time passes for an empty container too (replicas appended later start here)
     if (R == 0 || timesteps == 0) return ISINGMC_OK;
+    if (s->packed) return pk_run_steps(s, timesteps, betas, beta_stride, energies_per_step, device_ms, sync);
     const bool lattice = g->kind == ISINGMC_KIND_LATTICE2D;
 
     // per-step energies on the lattice path: integer counters per (step, replica), converted at the
@@ -982,6 +1238,7 @@ extern "C" int isingmc_get_packed_states(isingmc_states *s, uint32_t *words_out)
     if (!s || !words_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     TRY(use_device(s->g->device));
     if (s->R == 0) return ISINGMC_OK;
+    if (s->packed) return pk_get_states(s, nullptr, 0, words_out);
     HIP_TRY(hipMemcpyAsync(words_out, s->d_state, s->R * s->g->state_words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
@@ -993,6 +1250,7 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
     if (replica_stride_bytes < s->g->nvars) return fail(ISINGMC_ERR_INVALID, "replica stride smaller than nvars");
     TRY(use_device(s->g->device));
     const isingmc_graph *g = s->g;
+    if (s->packed) return s->R ? pk_get_states(s, states_out, replica_stride_bytes, nullptr) : ISINGMC_OK;
     // packed device words -> host, in slabs of replicas, unpacked to bytes by host threads
     const size_t slab = std::max<size_t>(1, std::min<size_t>(s->R, (size_t(256) << 20) / (g->state_words * 4)));
     std::vector<uint32_t> words(slab * g->state_words);
@@ -1031,6 +1289,7 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
 {
     if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
+    if (s->g->kind != ISINGMC_KIND_LATTICE2D) return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path");
     if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
         return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
     for (size_t i = 0; i < n_rungs; i++)

@@ -1,0 +1,199 @@
+// Replica-packed path for arbitrary graphs with uniform |J|, no fields and degree <= 6 (3-d cubic,
+// triangular, honeycomb, diluted or odd-sized square lattices, random regular graphs ...): the general
+// edge-list path of BASELINE config c5 at bit-sliced speed.  DESIGN.md S6.
+//
+// Layout: the SAME colour-major positions as the thread-per-site general path, but one 32-bit word per
+// POSITION holding the spins of the 32 replicas of a group (bit b = replica 32g+b).  A neighbour gather
+// is then one word for 32 replicas, the satisfied-bond count of a site is a bit-sliced 3-bit counter,
+// and the acceptance test is the lattice kernel's: bit-planes of uniform prefixes compared MSB-first
+// against per-class thresholds, ties resolved with 32 more bits.  Flipping a spin with k satisfied
+// bonds out of deg costs dE = 2|J| m, m = 2k - deg: m <= 0 always flips, m = 1..6 flips with
+// probability exp(-beta 2|J| m).  One thread owns 4 consecutive positions (a position-quad): Philox
+// call p yields plane p for those 4 words.
+//
+// Threshold table per replica group (uint32[PK_TAB_WORDS]), built on the host:
+//   all[m-1]            bit r: replica r accepts class m outright (T = 2^THR_BITS)
+//   tbw[m-1][p]         bit r: bit p (MSB first) of the top N_PLANES bits of T_m(beta_r)
+//   lo[m-1][r]          low 32 bits of T_m(beta_r)
+#pragma once
+#include "lattice_kernels.hpp"
+
+namespace isingmc {
+
+constexpr int PK_MAX_DEG = 6;
+constexpr uint32_t DOM_PK_SWEEP = 0x504B5357u; // "PKSW"
+constexpr uint32_t DOM_PK_INIT = 0x504B494Eu;  // "PKIN"
+constexpr uint32_t PK_TAB_ALL = 0, PK_TAB_TBW = PK_MAX_DEG, PK_TAB_LO = PK_MAX_DEG + PK_MAX_DEG * N_PLANES;
+constexpr uint32_t PK_TAB_WORDS = PK_TAB_LO + PK_MAX_DEG * 32;
+
+struct PkGraphDev {
+    const uint32_t *rowptr;     // n_pos + 1
+    const uint32_t *nbr_sgn;    // neighbour position | (J > 0) << 31
+    const uint32_t *site;       // original site per position, PAD_SITE on padding
+    const uint32_t *class_base; // n_colours + 1
+    uint32_t n_colours;
+    uint32_t n_pos;             // multiple of 64
+};
+
+// satisfied-bond count of the 32 replicas at position p, bit-sliced (c0 = LSB)
+__device__ __forceinline__ void pk_count(const PkGraphDev &G, const uint32_t *__restrict__ st, uint32_t p, uint32_t s,
+                                         uint32_t &deg, uint32_t &c0, uint32_t &c1, uint32_t &c2)
+{
+    const uint32_t b = G.rowptr[p], e = G.rowptr[p + 1];
+    deg = e - b;
+    c0 = c1 = c2 = 0;
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t x = G.nbr_sgn[i];
+        const uint32_t n = st[x & 0x7FFFFFFFu];
+        const uint32_t sat = (s ^ n) ^ ((x >> 31) ? 0u : 0xFFFFFFFFu); // J>0: satisfied when the spins differ
+        const uint32_t k0 = c0 & sat;
+        c0 ^= sat;
+        const uint32_t k1 = c1 & k0;
+        c1 ^= k0;
+        c2 ^= k1;
+    }
+}
+
+// replicas whose count equals k
+__device__ __forceinline__ uint32_t pk_match(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k)
+{
+    return ~((c0 ^ (0u - (k & 1u))) | (c1 ^ (0u - ((k >> 1) & 1u))) | (c2 ^ (0u - ((k >> 2) & 1u))));
+}
+
+// one colour class of one timestep; blockIdx.y = replica group
+__global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+                                                       const uint32_t class_begin, const uint32_t class_end,
+                                                       const uint64_t t, const uint2 *__restrict__ group_keys,
+                                                       const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
+{
+    const uint32_t g = blockIdx.y;
+    const uint32_t p0 = class_begin + 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (p0 >= class_end) return;
+    uint32_t *st = state + size_t(g) * G.n_pos;
+    const uint32_t *tab = tabs + size_t(g) * tab_stride;
+    const uint2 key = group_keys[g];
+    const uint32_t PQ = p0 >> 2;
+
+    // the (up to) three costly classes of a site: m_j = 2j + 2 - (deg & 1), k_j = deg/2 + 1 + j
+    uint32_t own[4], eq[4][3], mrow[4][3], lt[4], und[4], always[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t p = p0 + q;
+        own[q] = st[p];
+        uint32_t deg, c0, c1, c2;
+        pk_count(G, st, p, own[q], deg, c0, c1, c2);
+        const uint32_t valid = G.site[p] != PAD_SITE ? 0xFFFFFFFFu : 0u;
+        uint32_t costly = 0;
+        lt[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t k = (deg >> 1) + 1 + j, m = 2 * j + 2 - (deg & 1u);
+            eq[q][j] = k <= deg ? pk_match(c0, c1, c2, k) : 0u;
+            mrow[q][j] = m - 1; // row of the threshold table
+            costly |= eq[q][j];
+            lt[q] |= eq[q][j] & tab[PK_TAB_ALL + m - 1];
+        }
+        always[q] = ~costly & valid; // m <= 0 flips outright; padding never flips
+        und[q] = costly & ~lt[q];
+    }
+
+    const uint32_t c0 = uint32_t(t), c1 = PQ;
+#pragma unroll
+    for (int pl = 0; pl < N_PLANES; pl++) {
+        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, pl), DOM_PK_SWEEP), key);
+        const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t tb = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) tb |= eq[q][j] & tab[PK_TAB_TBW + mrow[q][j] * N_PLANES + pl];
+            const uint32_t decided = und[q] & (rr[q] ^ tb);
+            lt[q] |= decided & tb;
+            und[q] ^= decided;
+        }
+    }
+
+    uint32_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = always[q] | lt[q];
+    if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
+        uint32_t nres = 0;
+        uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, N_PLANES), DOM_PK_SWEEP), key);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t mm = und[q];
+            while (mm) {
+                const uint32_t b = __ffs(mm) - 1;
+                mm &= mm - 1;
+                if (nres != 0 && (nres & 3u) == 0)
+                    rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, N_PLANES + (nres >> 2)), DOM_PK_SWEEP), key);
+                const uint32_t row = ((eq[q][0] >> b) & 1u) ? mrow[q][0] : ((eq[q][1] >> b) & 1u) ? mrow[q][1] : mrow[q][2];
+                if (sel4(rnd, nres & 3u) < tab[PK_TAB_LO + row * 32 + b]) acc[q] |= 1u << b;
+                nres++;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) st[p0 + q] = own[q] ^ acc[q];
+}
+
+// random start: word of position p = Philox(group key, (0, p>>2, 0, "PKIN"))[p&3]; padding positions 0
+__global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+                                                      const uint2 *__restrict__ group_keys, const uint32_t first_group)
+{
+    const uint32_t g = first_group + blockIdx.y;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= G.n_pos) return;
+    const uint4 rnd = philox4x32_10(make_uint4(0, p >> 2, 0, DOM_PK_INIT), group_keys[g]);
+    state[size_t(g) * G.n_pos + p] = G.site[p] != PAD_SITE ? sel4(rnd, p & 3u) : 0u;
+}
+
+// Directed satisfied-bond total and up-spin count per replica.  Lane = (position stream, replica bit): the
+// 32 lanes of a half-wave read the SAME words (broadcast) and each extracts its own replica's bit.
+// out[2r] += satisfied (directed), out[2r+1] += up spins.
+__global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restrict__ state, const PkGraphDev G,
+                                                         unsigned long long *__restrict__ out, const uint32_t n_replicas)
+{
+    __shared__ uint32_t red[2][8][32];
+    const uint32_t g = blockIdx.y, bit = threadIdx.x & 31u, sub = threadIdx.x >> 5; // 8 position streams per block
+    const uint32_t *st = state + size_t(g) * G.n_pos;
+    uint32_t sat = 0, up = 0;
+    const uint32_t per_block = (G.n_pos + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per_block, end = min(G.n_pos, begin + per_block);
+    for (uint32_t p = begin + sub; p < end; p += 8) {
+        if (G.site[p] == PAD_SITE) continue;
+        const uint32_t s = st[p];
+        up += (s >> bit) & 1u;
+        for (uint32_t i = G.rowptr[p], e = G.rowptr[p + 1]; i < e; i++) {
+            const uint32_t x = G.nbr_sgn[i];
+            const uint32_t differ = ((s ^ st[x & 0x7FFFFFFFu]) >> bit) & 1u;
+            sat += differ ^ ((x >> 31) ? 0u : 1u);
+        }
+    }
+    red[0][sub][bit] = sat;
+    red[1][sub][bit] = up;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t r = 32 * g + threadIdx.x;
+        unsigned long long s = 0, u = 0;
+        for (int k = 0; k < 8; k++) { s += red[0][k][threadIdx.x]; u += red[1][k][threadIdx.x]; }
+        if (r < n_replicas && (s | u)) {
+            atomicAdd(out + 2 * size_t(r), s);
+            atomicAdd(out + 2 * size_t(r) + 1, u);
+        }
+    }
+}
+
+// write one replica's spins (bits[] packed by position, 32 positions per word) into bit `bit` of group g
+__global__ __launch_bounds__(256) void pk_set_replica_kernel(uint32_t *__restrict__ state, const uint32_t n_pos,
+                                                             const uint32_t *__restrict__ bits, const uint32_t g,
+                                                             const uint32_t bit)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pos) return;
+    uint32_t *w = state + size_t(g) * n_pos + p;
+    const uint32_t v = (bits[p >> 5] >> (p & 31u)) & 1u;
+    *w = (*w & ~(1u << bit)) | (v << bit);
+}
+
+} // namespace isingmc

@@ -294,3 +294,74 @@ def test_general_resident_kernel_equals_per_class_launches(capi, oracle, monkeyp
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12, atol=1e-9)
+
+
+def _packed_case(capi, oracle, ea, eb, ej, nvars, R, T, beta=None, beta_replica=None, initial=None):
+    seeds = capi.make_seeds(77, R)
+    g = capi.Graph(ea, eb, ej, nvars=nvars, force_general=True)
+    assert g.kind == capi.KIND_GENERAL
+    st = capi.States(g, seeds, initial_state=initial)
+    ref_states = None
+    if initial is not None:
+        ref_states = np.tile(np.asarray(initial, dtype=np.uint8), (32 * ((R + 31) // 32), 1))
+    if beta_replica is not None:
+        st.set_betas(beta_replica)
+        eps = st.do_time_steps(T, per_step_energies=True)
+        e_ref, s_ref, eps_ref = oracle.pk_run(ea, eb, ej, nvars, seeds, T, beta_replica=beta_replica, states=ref_states,
+                                              per_step=True)
+    else:
+        betas = [beta] * T if np.ndim(beta) == 0 else beta
+        eps = st.do_time_steps(T, beta, per_step_energies=True)
+        e_ref, s_ref, eps_ref = oracle.pk_run(ea, eb, ej, nvars, seeds, T, betas=betas, states=ref_states, per_step=True)
+    np.testing.assert_array_equal(st.states().astype(np.uint8), s_ref[:R])
+    np.testing.assert_allclose(eps, eps_ref, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(st.energies(), e_ref, rtol=1e-12, atol=1e-9)
+    mags = st.magnetisations()
+    np.testing.assert_array_equal(mags, 2 * s_ref[:R].sum(axis=1).astype(np.int64) - nvars)
+    return st, s_ref
+
+
+def test_packed_general_path_bit_exact(capi, oracle, exact, monkeypatch):
+    """Replica-packed general path (uniform |J|, degree <= 6) against oracle engine D."""
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    ea, eb, ej = exact.cubic_lattice_edges(8, -1.0)                          # BASELINE c5's shape, small
+    _packed_case(capi, oracle, ea, eb, ej, 512, R=40, T=8, beta=0.2217)     # partial last group
+    _packed_case(capi, oracle, ea, eb, ej, 512, R=64, T=5, beta=np.linspace(0.1, 0.6, 5))
+    _packed_case(capi, oracle, ea, eb, ej, 512, R=3, T=6, beta=0.0)
+    ea2, eb2, ej2 = exact.square_lattice_edges(10, 6, 0.7, np.random.default_rng(4))   # +-J, not 64-wide
+    _packed_case(capi, oracle, ea2, eb2, ej2, 60, R=33, T=10, beta=0.9)
+    rng = np.random.default_rng(8)                                           # irregular degrees, isolated sites
+    n = 150
+    pairs = set()
+    deg = np.zeros(n, dtype=int)
+    while len(pairs) < 260:
+        a, b = rng.integers(0, n - 10, 2)
+        if a != b and deg[a] < 6 and deg[b] < 6 and (min(a, b), max(a, b)) not in pairs:
+            pairs.add((min(a, b), max(a, b))); deg[a] += 1; deg[b] += 1
+    ea3 = np.array([p[0] for p in pairs], dtype=np.uint64)
+    eb3 = np.array([p[1] for p in pairs], dtype=np.uint64)
+    ej3 = rng.choice([-1.5, 1.5], len(pairs))
+    _packed_case(capi, oracle, ea3, eb3, ej3, n, R=50, T=12, beta=0.4)
+    _packed_case(capi, oracle, ea3, eb3, ej3, n, R=50, T=7, beta_replica=np.linspace(0.05, 1.5, 50))
+    ini = (rng.integers(0, 2, n)).astype(np.uint8)
+    st, s_ref = _packed_case(capi, oracle, ea3, eb3, ej3, n, R=35, T=4, beta=0.6, initial=ini)
+    other = 1 - ini
+    st.set_state(33, other)                                                  # one replica of the second group
+    got = st.states().astype(np.uint8)
+    assert np.array_equal(got[33], other) and np.array_equal(got[32], s_ref[32]) and np.array_equal(got[34], s_ref[34])
+    with pytest.raises(ValueError, match="cannot grow"):
+        st.append(5)
+
+
+def test_packed_path_equilibrium_vs_kaufman(capi, exact, monkeypatch):
+    """K3 for the packed path: 32x32 torus (general path: not 64-wide), 64 replicas."""
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    L, beta, R = 32, 0.35, 64
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    st = capi.States(g, capi.make_seeds(5, R))
+    st.do_time_steps(400, beta)
+    per_replica = st.do_time_steps(1500, beta, per_step_energies=True).mean(axis=1)
+    mean, err = per_replica.mean(), per_replica.std(ddof=1) / np.sqrt(R)
+    ref = exact.kaufman_energy(L, L, beta)
+    assert abs(mean - ref) < 4.5 * err, (mean, ref, err)

@@ -81,7 +81,7 @@ def c5(steps):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for a in sys.argv[1:] if a in ("c3", "c4", "c5")]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     for name in args or ["c3", "c4", "c5"]:
         fn = {"c3": c3, "c4": c4, "c5": c5}[name]
