@@ -518,7 +518,7 @@ typedef struct {
     uint32_t *colour;   /* per site */
     uint32_t ncolours;
     size_t *class_base; /* first packed position of each colour class, ncolours+1 */
-    size_t *pos;        /* site -> packed position (colour-major, classes padded to 64) */
+    size_t *pos;        /* site -> packed position (colour-major, classes padded to 256) */
     size_t npos;
 } gen_graph;
 
@@ -550,7 +550,7 @@ static void gen_build(gen_graph *G, size_t n_edges, const uint64_t *ea, const ui
     for (size_t i = 0; i < nvars; i++) count[G->colour[i]]++;
     G->class_base = malloc((nc + 1) * sizeof(size_t));
     G->class_base[0] = 0;
-    for (uint32_t c = 0; c < nc; c++) G->class_base[c + 1] = G->class_base[c] + ((count[c] + 63) / 64) * 64;
+    for (uint32_t c = 0; c < nc; c++) G->class_base[c + 1] = G->class_base[c] + ((count[c] + 255) / 256) * 256;
     G->npos = G->class_base[nc];
     G->pos = malloc(nvars * sizeof(size_t));
     memset(count, 0, nc * sizeof(size_t));
@@ -705,19 +705,21 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
             for (size_t i = 0; i < nvars; i++) {
                 size_t p = G.pos[i];
                 uint32_t r[4];
-                philox_seeded(key, 0, (uint32_t)(p >> 2), 0, DOM_PK_INIT, r);
-                for (int b = 0; b < 32; b++) S[(size_t)b * nvars + i] = (uint8_t)((r[p & 3] >> b) & 1u);
+                size_t q = (p & 255) >> 6; /* position p is word q of the quad led by p - 64 q */
+                philox_seeded(key, 0, (uint32_t)(p - 64 * q), 0, DOM_PK_INIT, r);
+                for (int b = 0; b < 32; b++) S[(size_t)b * nvars + i] = (uint8_t)((r[q] >> b) & 1u);
             }
         for (size_t k = 0; k < timesteps; k++) {
             uint64_t t = t0 + k;
             for (uint32_t c = 0; c < G.ncolours; c++)
-                for (size_t p0 = G.class_base[c]; p0 < G.class_base[c + 1]; p0 += 4) {
+                /* position-quads: leader p0 (offset < 64 inside its 256-block), members p0 + 64 q */
+                for (size_t p0 = G.class_base[c]; p0 < G.class_base[c + 1]; p0 += ((p0 & 63) == 63 ? 193 : 1)) {
                     uint32_t planes[N_PLANES][4], tie_words[4];
                     unsigned n_ties = 0;
                     for (uint32_t pl = 0; pl < N_PLANES; pl++)
-                        philox_seeded(key, (uint32_t)t, (uint32_t)(p0 >> 2), ctr2(t, 0, pl), DOM_PK_SWEEP, planes[pl]);
+                        philox_seeded(key, (uint32_t)t, (uint32_t)p0, ctr2(t, 0, pl), DOM_PK_SWEEP, planes[pl]);
                     for (int q = 0; q < 4; q++) {
-                        size_t i = site_of[p0 + q];
+                        size_t i = site_of[p0 + 64 * q];
                         if (i == (size_t)-1) continue;
                         int deg = (int)(G.A.ptr[i + 1] - G.A.ptr[i]);
                         for (int b = 0; b < 32; b++) {
@@ -739,7 +741,7 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
                                 else if (upre > hi) accept = 0;
                                 else {
                                     if ((n_ties & 3) == 0)
-                                        philox_seeded(key, (uint32_t)t, (uint32_t)(p0 >> 2),
+                                        philox_seeded(key, (uint32_t)t, (uint32_t)p0,
                                                       ctr2(t, 0, N_PLANES + n_ties / 4), DOM_PK_SWEEP, tie_words);
                                     accept = tie_words[n_ties & 3] < lo;
                                     n_ties++;

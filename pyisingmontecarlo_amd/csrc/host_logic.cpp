@@ -183,7 +183,7 @@ Colouring greedy_colouring(const Adjacency &A, size_t nvars)
     std::vector<uint64_t> count(nc, 0);
     for (size_t i = 0; i < nvars; i++) count[C.colour[i]]++;
     C.class_base.assign(nc + 1, 0);
-    for (uint32_t c = 0; c < nc; c++) C.class_base[c + 1] = C.class_base[c] + (count[c] + 63) / 64 * 64;
+    for (uint32_t c = 0; c < nc; c++) C.class_base[c + 1] = C.class_base[c] + (count[c] + 255) / 256 * 256; // whole waves (64) and wave-strided position-quads (4 x 64)
     C.n_pos = C.class_base[nc];
     C.pos.resize(nvars);
     std::fill(count.begin(), count.end(), 0);

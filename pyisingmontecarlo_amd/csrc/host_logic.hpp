@@ -48,7 +48,7 @@ Adjacency build_adjacency(const uint64_t *ea, const uint64_t *eb, const double *
 struct Colouring {
     std::vector<uint32_t> colour;     // per site
     uint32_t n_colours = 0;
-    std::vector<uint64_t> class_base; // n_colours + 1, packed positions, classes padded to 64
+    std::vector<uint64_t> class_base; // n_colours + 1, packed positions, classes padded to 256
     std::vector<uint64_t> pos;        // site -> packed position
     uint64_t n_pos = 0;
 };

@@ -449,11 +449,12 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
         for (double x : w) uniform &= std::fabs(x) == jabs;
         uniform &= jabs > 0.0;
         if (uniform) {
-            std::vector<uint32_t> nbr_sgn(nbr.size());
-            for (size_t e = 0; e < nbr.size(); e++) nbr_sgn[e] = nbr[e] | (w[e] > 0.0 ? 0x80000000u : 0u);
+            std::vector<uint32_t> ell(size_t(PK_MAX_DEG) * n_pos, PK_NO_NBR); // slot-major: coalesced per slot
+            for (uint32_t p = 0; p < n_pos; p++)
+                for (uint32_t e = rowptr[p]; e < rowptr[p + 1]; e++)
+                    ell[size_t(e - rowptr[p]) * n_pos + p] = nbr[e] | (w[e] > 0.0 ? 0x80000000u : 0u);
             PkGraphDev &P = g->pk;
-            TRY(graph_upload(g, &P.nbr_sgn, nbr_sgn));
-            P.rowptr = D.rowptr;
+            TRY(graph_upload(g, &P.nbr_ell, ell));
             P.site = D.site;
             P.class_base = D.class_base;
             P.n_colours = D.n_colours;
@@ -793,7 +794,7 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
         if (e == b) continue;
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
-            hipLaunchKernelGGL(pk_sweep_kernel, dim3(((e - b) / 4 + 255) / 256, unsigned(ng)), dim3(256), 0, s->stream,
+            hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - b) / 1024 + ((e - b) % 1024 != 0), unsigned(ng)), dim3(256), 0, s->stream,
                                s->d_state + g0 * g->pk.n_pos, g->pk, b, e, s->t, s->d_keys + g0,
                                tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
         }

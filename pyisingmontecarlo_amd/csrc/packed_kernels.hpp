@@ -8,8 +8,12 @@
 // and the acceptance test is the lattice kernel's: bit-planes of uniform prefixes compared MSB-first
 // against per-class thresholds, ties resolved with 32 more bits.  Flipping a spin with k satisfied
 // bonds out of deg costs dE = 2|J| m, m = 2k - deg: m <= 0 always flips, m = 1..6 flips with
-// probability exp(-beta 2|J| m).  One thread owns 4 consecutive positions (a position-quad): Philox
-// call p yields plane p for those 4 words.
+// probability exp(-beta 2|J| m).  One thread owns a position-quad = the 4 positions p, p+64, p+128, p+192
+// of a 256-position block (p = the quad's leader): Philox call pl yields plane pl for those 4 words, and
+// for a fixed word q the 64 lanes of a wavefront touch 64 CONSECUTIVE positions -- every load (own word,
+// ELL neighbour slot, neighbour gather on regular lattices) is a fully coalesced 256-byte access.
+// Neighbours are stored ELL-style, slot-major: nbr_ell[i * n_pos + p] = position | (J>0) << 31, or
+// PK_NO_NBR for the unused slots of a site with fewer than PK_MAX_DEG neighbours.
 //
 // Threshold table per replica group (uint32[PK_TAB_WORDS]), built on the host:
 //   all[m-1]            bit r: replica r accepts class m outright (T = 2^THR_BITS)
@@ -26,26 +30,32 @@ constexpr uint32_t DOM_PK_INIT = 0x504B494Eu;  // "PKIN"
 constexpr uint32_t PK_TAB_ALL = 0, PK_TAB_TBW = PK_MAX_DEG, PK_TAB_LO = PK_MAX_DEG + PK_MAX_DEG * N_PLANES;
 constexpr uint32_t PK_TAB_WORDS = PK_TAB_LO + PK_MAX_DEG * 32;
 
+constexpr uint32_t PK_NO_NBR = 0xFFFFFFFFu;
+
 struct PkGraphDev {
-    const uint32_t *rowptr;     // n_pos + 1
-    const uint32_t *nbr_sgn;    // neighbour position | (J > 0) << 31
+    const uint32_t *nbr_ell;    // [PK_MAX_DEG][n_pos]: neighbour position | (J > 0) << 31, or PK_NO_NBR
     const uint32_t *site;       // original site per position, PAD_SITE on padding
-    const uint32_t *class_base; // n_colours + 1
+    const uint32_t *class_base; // n_colours + 1, multiples of 256
     uint32_t n_colours;
-    uint32_t n_pos;             // multiple of 64
+    uint32_t n_pos;             // multiple of 256
 };
 
-// satisfied-bond count of the 32 replicas at position p, bit-sliced (c0 = LSB)
+// satisfied-bond count of the 32 replicas at position p, bit-sliced (c0 = LSB).  Fixed trip count with
+// predication: the slot loads and then the state gathers of all neighbours are issued back to back.
 __device__ __forceinline__ void pk_count(const PkGraphDev &G, const uint32_t *__restrict__ st, uint32_t p, uint32_t s,
                                          uint32_t &deg, uint32_t &c0, uint32_t &c1, uint32_t &c2)
 {
-    const uint32_t b = G.rowptr[p], e = G.rowptr[p + 1];
-    deg = e - b;
-    c0 = c1 = c2 = 0;
-    for (uint32_t i = b; i < e; i++) {
-        const uint32_t x = G.nbr_sgn[i];
-        const uint32_t n = st[x & 0x7FFFFFFFu];
-        const uint32_t sat = (s ^ n) ^ ((x >> 31) ? 0u : 0xFFFFFFFFu); // J>0: satisfied when the spins differ
+    uint32_t x[PK_MAX_DEG], n[PK_MAX_DEG];
+#pragma unroll
+    for (int i = 0; i < PK_MAX_DEG; i++) x[i] = G.nbr_ell[size_t(i) * G.n_pos + p];
+#pragma unroll
+    for (int i = 0; i < PK_MAX_DEG; i++) n[i] = st[x[i] == PK_NO_NBR ? p : (x[i] & 0x7FFFFFFFu)];
+    c0 = c1 = c2 = deg = 0;
+#pragma unroll
+    for (int i = 0; i < PK_MAX_DEG; i++) {
+        const bool used = x[i] != PK_NO_NBR;
+        deg += used;
+        const uint32_t sat = used ? (s ^ n[i]) ^ ((x[i] >> 31) ? 0u : 0xFFFFFFFFu) : 0u; // J>0: satisfied when the spins differ
         const uint32_t k0 = c0 & sat;
         c0 ^= sat;
         const uint32_t k1 = c1 & k0;
@@ -67,33 +77,36 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
                                                        const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
 {
     const uint32_t g = blockIdx.y;
-    const uint32_t p0 = class_begin + 4 * (blockIdx.x * 256 + threadIdx.x);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x; // wave w of the class owns positions [256w, 256w+256)
+    const uint32_t p0 = class_begin + 256 * (tid >> 6) + (tid & 63u); // the quad's leader
     if (p0 >= class_end) return;
     uint32_t *st = state + size_t(g) * G.n_pos;
     const uint32_t *tab = tabs + size_t(g) * tab_stride;
     const uint2 key = group_keys[g];
-    const uint32_t PQ = p0 >> 2;
+    const uint32_t PQ = p0; // Philox counter word of the quad
 
-    // the (up to) three costly classes of a site: m_j = 2j + 2 - (deg & 1), k_j = deg/2 + 1 + j
-    uint32_t own[4], eq[4][3], mrow[4][3], lt[4], und[4], always[4];
+    // the (up to) three costly classes of a site: m_j = 2j + 2 - (deg & 1), k_j = deg/2 + 1 + j, i.e. table
+    // row 2j for odd degrees and 2j+1 for even ones.  The table is uniform per workgroup (scalar loads);
+    // the per-lane part is only the parity select.  Padding positions have degree 0 and flip freely:
+    // nothing reads them.
+    uint32_t own[4], eq[4][3], odd[4], lt[4], und[4], always[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t p = p0 + q;
+        const uint32_t p = p0 + 64 * q;
         own[q] = st[p];
         uint32_t deg, c0, c1, c2;
         pk_count(G, st, p, own[q], deg, c0, c1, c2);
-        const uint32_t valid = G.site[p] != PAD_SITE ? 0xFFFFFFFFu : 0u;
+        odd[q] = 0u - (deg & 1u);
         uint32_t costly = 0;
         lt[q] = 0;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const uint32_t k = (deg >> 1) + 1 + j, m = 2 * j + 2 - (deg & 1u);
+            const uint32_t k = (deg >> 1) + 1 + j;
             eq[q][j] = k <= deg ? pk_match(c0, c1, c2, k) : 0u;
-            mrow[q][j] = m - 1; // row of the threshold table
             costly |= eq[q][j];
-            lt[q] |= eq[q][j] & tab[PK_TAB_ALL + m - 1];
+            lt[q] |= eq[q][j] & ((odd[q] & tab[PK_TAB_ALL + 2 * j]) | (~odd[q] & tab[PK_TAB_ALL + 2 * j + 1]));
         }
-        always[q] = ~costly & valid; // m <= 0 flips outright; padding never flips
+        always[q] = ~costly; // m <= 0 flips outright
         und[q] = costly & ~lt[q];
     }
 
@@ -102,11 +115,17 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
     for (int pl = 0; pl < N_PLANES; pl++) {
         const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, pl), DOM_PK_SWEEP), key);
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+        uint32_t t_odd[3], t_even[3]; // wave-uniform threshold bit-planes of the six classes
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            t_odd[j] = tab[PK_TAB_TBW + (2 * j) * N_PLANES + pl];
+            t_even[j] = tab[PK_TAB_TBW + (2 * j + 1) * N_PLANES + pl];
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t tb = 0;
 #pragma unroll
-            for (int j = 0; j < 3; j++) tb |= eq[q][j] & tab[PK_TAB_TBW + mrow[q][j] * N_PLANES + pl];
+            for (int j = 0; j < 3; j++) tb |= eq[q][j] & ((odd[q] & t_odd[j]) | (~odd[q] & t_even[j]));
             const uint32_t decided = und[q] & (rr[q] ^ tb);
             lt[q] |= decided & tb;
             und[q] ^= decided;
@@ -127,25 +146,28 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
                 mm &= mm - 1;
                 if (nres != 0 && (nres & 3u) == 0)
                     rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, N_PLANES + (nres >> 2)), DOM_PK_SWEEP), key);
-                const uint32_t row = ((eq[q][0] >> b) & 1u) ? mrow[q][0] : ((eq[q][1] >> b) & 1u) ? mrow[q][1] : mrow[q][2];
+                const uint32_t j = ((eq[q][0] >> b) & 1u) ? 0u : ((eq[q][1] >> b) & 1u) ? 1u : 2u;
+                const uint32_t row = 2 * j + 1 - (odd[q] & 1u);
                 if (sel4(rnd, nres & 3u) < tab[PK_TAB_LO + row * 32 + b]) acc[q] |= 1u << b;
                 nres++;
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) st[p0 + q] = own[q] ^ acc[q];
+    for (int q = 0; q < 4; q++) st[p0 + 64 * q] = own[q] ^ acc[q];
 }
 
-// random start: word of position p = Philox(group key, (0, p>>2, 0, "PKIN"))[p&3]; padding positions 0
+// random start: position p is word q = (p & 255) >> 6 of its quad (leader p - 64 q):
+// word = Philox(group key, (0, leader, 0, "PKIN"))[q]; padding positions 0
 __global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
                                                       const uint2 *__restrict__ group_keys, const uint32_t first_group)
 {
     const uint32_t g = first_group + blockIdx.y;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= G.n_pos) return;
-    const uint4 rnd = philox4x32_10(make_uint4(0, p >> 2, 0, DOM_PK_INIT), group_keys[g]);
-    state[size_t(g) * G.n_pos + p] = G.site[p] != PAD_SITE ? sel4(rnd, p & 3u) : 0u;
+    const uint32_t q = (p & 255u) >> 6;
+    const uint4 rnd = philox4x32_10(make_uint4(0, p - 64 * q, 0, DOM_PK_INIT), group_keys[g]);
+    state[size_t(g) * G.n_pos + p] = G.site[p] != PAD_SITE ? sel4(rnd, q) : 0u;
 }
 
 // Directed satisfied-bond total and up-spin count per replica.  Lane = (position stream, replica bit): the
@@ -164,8 +186,10 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
         if (G.site[p] == PAD_SITE) continue;
         const uint32_t s = st[p];
         up += (s >> bit) & 1u;
-        for (uint32_t i = G.rowptr[p], e = G.rowptr[p + 1]; i < e; i++) {
-            const uint32_t x = G.nbr_sgn[i];
+#pragma unroll
+        for (int i = 0; i < PK_MAX_DEG; i++) {
+            const uint32_t x = G.nbr_ell[size_t(i) * G.n_pos + p];
+            if (x == PK_NO_NBR) continue;
             const uint32_t differ = ((s ^ st[x & 0x7FFFFFFFu]) >> bit) & 1u;
             sat += differ ^ ((x >> 31) ? 0u : 1u);
         }
