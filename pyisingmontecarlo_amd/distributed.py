@@ -13,9 +13,17 @@ import numpy as np
 
 def shard_bounds(n, world, rank):
     """Contiguous block [lo, hi) of n replicas owned by `rank` (SURVEY.md 8e: replica r -> GPU r // ceil(R/G))."""
-    per = -(-n // world) if world > 0 else n
+    per = block_size(n, world)
     lo = min(n, rank * per)
     return lo, min(n, lo + per)
+
+
+def block_size(n, world):
+    """Replicas per rank: ceil(n / world), rounded up to a multiple of 32 once a rank holds >= 32 of them --
+    the replica-packed general path keys 32-replica groups, so its results are shard-invariant only for
+    blocks that start on a multiple of 32."""
+    per = -(-n // world) if world > 0 else n
+    return -(-per // 32) * 32 if per >= 32 else per
 
 
 def _dist():
@@ -87,7 +95,7 @@ def run_monte_carlo(lattice, beta, timesteps, num_experiments, group=None, **kwa
     world, rank = world_rank(group)
     lo, hi = shard_bounds(num_experiments, world, rank)
     energies, states = lattice.run_monte_carlo(beta, timesteps, num_experiments, replica_range=(lo, hi), **kwargs)
-    per = -(-num_experiments // world)
+    per = block_size(num_experiments, world)
     all_e = all_gather_f64(energies, per, group)
     # blocks are contiguous and only the tail ranks can be short: drop the padding
     out = np.concatenate([all_e[r * per:r * per + (shard_bounds(num_experiments, world, r)[1] -

@@ -111,7 +111,7 @@ class ClassicalTempering:
         G = len(self._betas)
         if G == 0:
             raise ValueError("no graphs: call add_graph(beta) first")
-        self._per = -(-G // self._world)
+        self._per = D.block_size(G, self._world)
         self._lo, self._hi = D.shard_bounds(G, self._world, self._rank)
         self._engine = self._engine_factory()
         self._states = self._engine.make_states(np.array(self._slot_seeds[self._lo:self._hi], dtype=np.uint64))

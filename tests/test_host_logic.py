@@ -149,10 +149,14 @@ def test_pt_swap_round_matches_oracle(capi, oracle):
 
 
 def test_shard_bounds():
-    from pyisingmontecarlo_amd.distributed import shard_bounds
-    for n in (0, 1, 7, 8, 256, 513):
+    from pyisingmontecarlo_amd.distributed import block_size, shard_bounds
+    for n in (0, 1, 7, 8, 100, 256, 513, 1024):
         for world in (1, 2, 3, 8):
             blocks = [shard_bounds(n, world, r) for r in range(world)]
             assert blocks[0][0] == 0 and blocks[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
-            assert all(0 <= hi - lo <= -(-n // world) for lo, hi in blocks)
+            per = block_size(n, world)
+            assert per >= -(-n // world) and all(0 <= hi - lo <= per for lo, hi in blocks)
+            if n // world >= 32:                       # big blocks start on multiples of 32 (packed-path groups)
+                assert all(lo % 32 == 0 for lo, hi in blocks if hi > lo)
+    assert shard_bounds(256, 8, 3) == (96, 128) and shard_bounds(100, 2, 1) == (64, 100)
