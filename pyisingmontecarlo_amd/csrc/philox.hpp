@@ -12,18 +12,35 @@ constexpr uint32_t DOM_LAT_INIT = 0x4C415449u;  // "LATI"
 constexpr uint32_t DOM_GEN_SWEEP = 0x47454E53u; // "GENS"
 constexpr uint32_t DOM_GEN_INIT = 0x47454E49u;  // "GENI"
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+// One Philox round.  VECTOR_XOR3: hi ^ ctr ^ key as ONE v_bitop3_b32 (truth table 0x96); hipcc emits two
+// v_xor for the plain expression.  The builtin pins its operands to the vector unit, so it is used only
+// where the operands are lane-varying anyway (see below).
+template <bool VECTOR_XOR3>
+__device__ __forceinline__ void philox_round(uint4 &c, uint2 &k)
 {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = uint64_t(0xD2511F53u) * c.x;
-        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c.z;
-        // hi ^ ctr ^ key as ONE v_bitop3_b32 (truth table 0x96 = 3-input xor); hipcc emits two v_xor
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c.x;
+    const uint64_t p1 = uint64_t(0xCD9E8D57u) * c.z;
+    if constexpr (VECTOR_XOR3)
         c = make_uint4(__builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c.y, k.x, 0x96), uint32_t(p1),
                        __builtin_amdgcn_bitop3_b32(uint32_t(p0 >> 32), c.w, k.y, 0x96), uint32_t(p0));
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
+    else
+        c = make_uint4(uint32_t(p1 >> 32) ^ c.y ^ k.x, uint32_t(p1), uint32_t(p0 >> 32) ^ c.w ^ k.y, uint32_t(p0));
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+}
+
+// Every call site keeps the lane-varying index in counter word 1 (c.y) and everything else wave-uniform.
+// The variation then reaches the multiplied words only gradually: round 1 is entirely uniform, rounds 2
+// and 3 have one uniform multiply each.  Those rounds are written with plain xors so that hipcc keeps
+// their uniform halves on the scalar unit (s_mul_hi_u32 / s_mul_i32 / s_xor); from round 4 on everything
+// varies and the xors are v_bitop3.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+    philox_round<false>(c, k);
+    philox_round<false>(c, k);
+    philox_round<false>(c, k);
+#pragma unroll
+    for (int r = 3; r < 10; r++) philox_round<true>(c, k);
     return c;
 }
 
