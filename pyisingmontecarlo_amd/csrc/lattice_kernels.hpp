@@ -170,7 +170,7 @@ __device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, co
     load_quad<VEC, UNI>(own_plane, oth_plane, g, colour, Q, qy, qxw, own, n, widx);
 
     // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
-    uint32_t eq4[4], lt[4], und[4], le2[4];
+    uint32_t eq3[4], eq4[4], lt[4], und[4], le2[4];
     // thresholds have THR_BITS = N_PLANES + 32 bits: the top N_PLANES are compared bit-sliced, the
     // low 32 against one residual Philox word
     const bool all3 = (thr.T3 >> THR_BITS) != 0, all4 = (thr.T4 >> THR_BITS) != 0;
@@ -181,10 +181,13 @@ __device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, co
         bond_masks<PMJ>(own[q], n, q, jn, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
         const uint32_t s01 = a0 ^ a1, c01 = a0 & a1, s23 = a2 ^ a3, c23 = a2 & a3;
         eq4[q] = c01 & c23;
-        const uint32_t eq3 = (c01 & s23) | (c23 & s01);
-        le2[q] = ~(eq3 | eq4[q]);
-        lt[q] = (all3 ? eq3 : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^THR_BITS: accepted outright
-        und[q] = (eq3 | eq4[q]) & ~lt[q];
+        eq3[q] = (c01 & s23) | (c23 & s01);
+        // pin the two class masks in registers: hipcc otherwise re-derives them from the bond masks inside
+        // every plane (7 instead of 5 instructions per word and plane)
+        asm("" : "+v"(eq3[q]), "+v"(eq4[q]));
+        le2[q] = ~(eq3[q] | eq4[q]);
+        lt[q] = (all3 ? eq3[q] : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^THR_BITS: accepted outright
+        und[q] = (eq3[q] | eq4[q]) & ~lt[q];
     }
 
     // N_PLANES bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
@@ -194,14 +197,27 @@ __device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, co
 #pragma unroll
     for (int p = 0; p < N_PLANES; p++) {
         const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, p), DOM_LAT_SWEEP), key);
-        const uint32_t m3 = 0u - ((hi3 >> (N_PLANES - 1 - p)) & 1u), m4 = 0u - ((hi4 >> (N_PLANES - 1 - p)) & 1u);
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t tb = (eq4[q] & m4) | (~eq4[q] & m3);
+        // threshold bit of this plane for class 3 / class 4: wave-uniform, so the per-spin threshold word is
+        // one of {0, eq3, eq4, eq3|eq4} -- a scalar branch picks the register, 3 instructions per word remain
+        const uint32_t sel = __builtin_amdgcn_readfirstlane(((hi3 >> (N_PLANES - 1 - p)) & 1u) | (((hi4 >> (N_PLANES - 1 - p)) & 1u) << 1));
+        auto step = [&](int q, uint32_t tb) {
             const uint32_t decided = und[q] & (rr[q] ^ tb); // random bit differs from threshold bit
             lt[q] |= decided & tb;                          // ... and it is the smaller one
             und[q] ^= decided;
+        };
+        if (sel == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) und[q] &= ~rr[q];
+        } else if (sel == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) step(q, eq3[q]);
+        } else if (sel == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) step(q, eq4[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) step(q, eq3[q] | eq4[q]);
         }
     }
 
