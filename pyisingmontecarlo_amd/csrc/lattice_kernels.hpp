@@ -71,10 +71,43 @@ __device__ __forceinline__ void thread_to_quad(const LatGeom &g, uint32_t gid, u
     }
 }
 
+// Where the two planes of a replica live.  PtrPlanes: plain pointers (LDS in the resident kernel, or global).
+// BufPlanes: one buffer descriptor per replica (wave-uniform, in SGPRs) + 32-bit byte offsets -- the address
+// arithmetic of the streaming kernel shrinks from 64-bit VALU adds per access to one 32-bit offset.
+struct PtrPlanes {
+    uint32_t *own;
+    const uint32_t *oth;
+    __device__ __forceinline__ uint4 own4(uint32_t w) const { return *reinterpret_cast<const uint4 *>(own + w); }
+    __device__ __forceinline__ uint4 oth4(uint32_t w) const { return *reinterpret_cast<const uint4 *>(oth + w); }
+    __device__ __forceinline__ uint32_t own1(uint32_t w) const { return own[w]; }
+    __device__ __forceinline__ uint32_t oth1(uint32_t w) const { return oth[w]; }
+    __device__ __forceinline__ void store4(uint32_t w, uint4 v) const { *reinterpret_cast<uint4 *>(own + w) = v; }
+    __device__ __forceinline__ void store1(uint32_t w, uint32_t v) const { own[w] = v; }
+};
+
+struct BufPlanes {
+    __amdgpu_buffer_rsrc_t rsrc; // the replica's 2 * wpp words
+    uint32_t own_off, oth_off;   // byte offsets of the two planes
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ uint4 ld4(uint32_t byte_off) const
+    {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ uint4 own4(uint32_t w) const { return ld4(own_off + 4 * w); }
+    __device__ __forceinline__ uint4 oth4(uint32_t w) const { return ld4(oth_off + 4 * w); }
+    __device__ __forceinline__ uint32_t own1(uint32_t w) const { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, own_off + 4 * w, 0, 0); }
+    __device__ __forceinline__ uint32_t oth1(uint32_t w) const { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, oth_off + 4 * w, 0, 0); }
+    __device__ __forceinline__ void store4(uint32_t w, uint4 v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rsrc, own_off + 4 * w, 0, 0);
+    }
+    __device__ __forceinline__ void store1(uint32_t w, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, own_off + 4 * w, 0, 0); }
+};
+
 // Loads the 4 own words and the neighbour words of quad Q (row y, first word xw) in plane `colour`.
-template <bool VEC, bool UNI>
-__device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane,
-                                          const uint32_t *__restrict__ oth_plane, const LatGeom &g,
+template <bool VEC, bool UNI, typename Mem>
+__device__ __forceinline__ void load_quad(const Mem &mem, const LatGeom &g,
                                           uint32_t colour, uint32_t Q, uint32_t y, uint32_t xw, uint32_t own[4],
                                           QuadNbr &n, uint32_t widx[4])
 {
@@ -86,11 +119,11 @@ __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane
         bool odd = (y + colour) & 1u;
         if constexpr (UNI) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd));
         const uint32_t sx = odd ? (xw + 4 == g.wpr ? 0 : xw + 4) : (xw == 0 ? g.wpr : xw) - 1;
-        const uint4 o4 = *reinterpret_cast<const uint4 *>(own_plane + w0);
-        const uint4 c4 = *reinterpret_cast<const uint4 *>(oth_plane + w0);
-        const uint4 u4 = *reinterpret_cast<const uint4 *>(oth_plane + yu * g.wpr + xw);
-        const uint4 d4 = *reinterpret_cast<const uint4 *>(oth_plane + yd * g.wpr + xw);
-        const uint32_t sw = oth_plane[y * g.wpr + sx]; // issued with the other loads, not behind a branch
+        const uint4 o4 = mem.own4(w0);
+        const uint4 c4 = mem.oth4(w0);
+        const uint4 u4 = mem.oth4(yu * g.wpr + xw);
+        const uint4 d4 = mem.oth4(yd * g.wpr + xw);
+        const uint32_t sw = mem.oth1(y * g.wpr + sx); // issued with the other loads, not behind a branch
         own[0] = o4.x; own[1] = o4.y; own[2] = o4.z; own[3] = o4.w;
         n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
         n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
@@ -116,15 +149,15 @@ __device__ __forceinline__ void load_quad(const uint32_t *__restrict__ own_plane
             const uint32_t yu = (yy == 0 ? g.H : yy) - 1, yd = (yy + 1 == g.H) ? 0 : yy + 1;
             const uint32_t row = yy * g.wpr;
             widx[q] = w;
-            own[q] = own_plane[w];
-            n.ce[q] = oth_plane[w];
-            n.up[q] = oth_plane[yu * g.wpr + xx];
-            n.dn[q] = oth_plane[yd * g.wpr + xx];
+            own[q] = mem.own1(w);
+            n.ce[q] = mem.oth1(w);
+            n.up[q] = mem.oth1(yu * g.wpr + xx);
+            n.dn[q] = mem.oth1(yd * g.wpr + xx);
             if ((yy + colour) & 1) {
-                const uint32_t nxt = oth_plane[row + (xx + 1 == g.wpr ? 0 : xx + 1)];
+                const uint32_t nxt = mem.oth1(row + (xx + 1 == g.wpr ? 0 : xx + 1));
                 n.si[q] = (n.ce[q] >> 1) | (nxt << 31);
             } else {
-                const uint32_t prv = oth_plane[row + (xx == 0 ? g.wpr : xx) - 1];
+                const uint32_t prv = mem.oth1(row + (xx == 0 ? g.wpr : xx) - 1);
                 n.si[q] = (n.ce[q] << 1) | (prv >> 31);
             }
         }
@@ -156,9 +189,8 @@ __device__ __forceinline__ void bond_masks(const uint32_t own, const QuadNbr &n,
 // One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
 // plane `own_plane`, reading its neighbours from `oth_plane`.  The planes may live in HBM (sweep kernel)
 // or in LDS (resident kernel): the function only sees pointers.
-template <bool VEC, bool PMJ, bool UNI>
-__device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, const uint32_t *__restrict__ oth_plane,
-                                            const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
+template <bool VEC, bool PMJ, bool UNI, typename Mem>
+__device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
                                             const LatThr thr, const uint32_t *__restrict__ jn,
                                             const uint32_t jneg_uniform, const uint32_t gid)
 {
@@ -167,7 +199,7 @@ __device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, co
 
     uint32_t own[4], widx[4];
     QuadNbr n;
-    load_quad<VEC, UNI>(own_plane, oth_plane, g, colour, Q, qy, qxw, own, n, widx);
+    load_quad<VEC, UNI>(mem, g, colour, Q, qy, qxw, own, n, widx);
 
     // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
     uint32_t eq3[4], eq4[4], lt[4], und[4], le2[4];
@@ -248,11 +280,10 @@ __device__ __forceinline__ void update_quad(uint32_t *__restrict__ own_plane, co
     }
 
     if constexpr (VEC) {
-        *reinterpret_cast<uint4 *>(own_plane + widx[0]) =
-            make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]);
+        mem.store4(widx[0], make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]));
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) own_plane[widx[q]] = own[q] ^ acc[q];
+        for (int q = 0; q < 4; q++) mem.store1(widx[q], own[q] ^ acc[q]);
     }
 }
 
@@ -265,9 +296,11 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     const uint32_t r = blockIdx.y;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= g.nquads) return;
-    uint32_t *own_plane = state + size_t(r) * 2 * g.wpp + size_t(colour) * g.wpp;
-    const uint32_t *oth_plane = state + size_t(r) * 2 * g.wpp + size_t(1 - colour) * g.wpp;
-    update_quad<VEC, PMJ, UNI>(own_plane, oth_plane, g, colour, t, keys[r], thr_replica ? thr_replica[r] : thr_uniform,
+    BufPlanes mem;
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
+    mem.own_off = colour * g.wpp * 4u;
+    mem.oth_off = (1 - colour) * g.wpp * 4u;
+    update_quad<VEC, PMJ, UNI>(mem, g, colour, t, keys[r], thr_replica ? thr_replica[r] : thr_uniform,
                                PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid);
 }
 
@@ -307,7 +340,7 @@ __global__ __launch_bounds__(256) void lat_measure_kernel(
         uint32_t Q, qy, qxw, own[4], widx[4];
         thread_to_quad<false>(g, gid, Q, qy, qxw);
         QuadNbr n;
-        load_quad<VEC, false>(p0, p0 + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
+        load_quad<VEC, false>(PtrPlanes{const_cast<uint32_t *>(p0), p0 + g.wpp}, g, 0, Q, qy, qxw, own, n, widx);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t a0, a1, a2, a3;
@@ -362,7 +395,7 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
         const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
         for (uint32_t colour = 0; colour < 2; colour++) {
             for (uint32_t gid = tid; gid < g.nquads; gid += nthreads)
-                update_quad<VEC, PMJ, false>(planes + colour * g.wpp, planes + (1 - colour) * g.wpp, g, colour, t0 + k,
+                update_quad<VEC, PMJ, false>(PtrPlanes{planes + colour * g.wpp, planes + (1 - colour) * g.wpp}, g, colour, t0 + k,
                                              key, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform,
                                              gid);
             __syncthreads();
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
                 uint32_t Q, qy, qxw, own[4], widx[4];
                 thread_to_quad<false>(g, gid, Q, qy, qxw);
                 QuadNbr n;
-                load_quad<VEC, false>(planes, planes + g.wpp, g, 0, Q, qy, qxw, own, n, widx);
+                load_quad<VEC, false>(PtrPlanes{planes, planes + g.wpp}, g, 0, Q, qy, qxw, own, n, widx);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     uint32_t a0, a1, a2, a3;
