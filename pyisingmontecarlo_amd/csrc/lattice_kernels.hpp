@@ -119,11 +119,13 @@ __device__ __forceinline__ void load_quad(const Mem &mem, const LatGeom &g,
         bool odd = (y + colour) & 1u;
         if constexpr (UNI) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd));
         const uint32_t sx = odd ? (xw + 4 == g.wpr ? 0 : xw + 4) : (xw == 0 ? g.wpr : xw) - 1;
+        // row * wpr: a shift under the 2^k mapping (wpr = 4 << cols_log2), else a quarter-rate multiply
+        const auto row_base = [&](uint32_t row) { return UNI ? row << (uint32_t(g.cols_log2) + 2) : row * g.wpr; };
         const uint4 o4 = mem.own4(w0);
         const uint4 c4 = mem.oth4(w0);
-        const uint4 u4 = mem.oth4(yu * g.wpr + xw);
-        const uint4 d4 = mem.oth4(yd * g.wpr + xw);
-        const uint32_t sw = mem.oth1(y * g.wpr + sx); // issued with the other loads, not behind a branch
+        const uint4 u4 = mem.oth4(row_base(yu) + xw);
+        const uint4 d4 = mem.oth4(row_base(yd) + xw);
+        const uint32_t sw = mem.oth1(row_base(y) + sx); // issued with the other loads, not behind a branch
         own[0] = o4.x; own[1] = o4.y; own[2] = o4.z; own[3] = o4.w;
         n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
         n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
@@ -257,7 +259,11 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
     uint32_t acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = le2[q] | lt[q];
+#ifdef ISINGMC_TIMING_ONLY_NO_TIES // diagnostic build: what the tie stage costs (results are wrong without it)
+    if (false) {
+#else
     if (und[0] | und[1] | und[2] | und[3]) {
+#endif
         const uint32_t lo3 = uint32_t(thr.T3), lo4 = uint32_t(thr.T4);
         uint32_t nres = 0;
         // the first residual call is hoisted: inside the divergent per-word loops below it would be
