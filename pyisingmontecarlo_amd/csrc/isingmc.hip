@@ -532,6 +532,8 @@ static dim3 lat_grid(const isingmc_graph *g, uint32_t quads, size_t replicas)
 
 constexpr size_t MAX_GRID_Y = 32768;
 
+static int lanes_reserve(isingmc_states *s, size_t n);
+
 // replica-packed general path (defined further down)
 static bool choose_packed(const isingmc_graph *g, size_t n_replicas);
 static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const uint8_t *initial_state);
@@ -628,6 +630,7 @@ extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const 
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
+    TRY(lanes_reserve(s.get(), 2)); // created up front: the first multi-lane run must not pay for stream creation
     if (choose_packed(g, n_replicas)) {
         TRY(pk_create(s.get(), n_replicas, seeds, initial_state));
     } else {

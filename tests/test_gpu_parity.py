@@ -365,3 +365,24 @@ def test_packed_path_equilibrium_vs_kaufman(capi, exact, monkeypatch):
     mean, err = per_replica.mean(), per_replica.std(ddof=1) / np.sqrt(R)
     ref = exact.kaufman_energy(L, L, beta)
     assert abs(mean - ref) < 4.5 * err, (mean, ref, err)
+
+
+def test_packed_path_is_selected_for_large_uniform_graphs(capi, oracle, exact):
+    """No env override: >= 16 experiments on a uniform-|J| graph too big for the LDS-resident kernel take
+    the replica-packed path (600x600 torus: not 64-wide, 360 000 sites), and match oracle engine D."""
+    W = H = 600
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    seeds = capi.make_seeds(9, 32)
+    g = capi.Graph(ea, eb, ej)
+    assert g.kind == capi.KIND_GENERAL
+    st = capi.States(g, seeds)
+    st.do_time_steps(3, 0.44)
+    e_ref, s_ref = oracle.pk_run(ea, eb, ej, W * H, seeds, 3, betas=[0.44] * 3)
+    np.testing.assert_array_equal(st.states().astype(np.uint8), s_ref[:32])
+    np.testing.assert_array_equal(st.energies(), e_ref)
+    # fewer than 16 experiments: thread-per-site path (oracle engine C)
+    st2 = capi.States(g, seeds[:2])
+    st2.do_time_steps(2, 0.44)
+    for r in range(2):
+        _, s_c = oracle.gen_run(ea, eb, ej, W * H, seeds[r], [0.44] * 2)
+        np.testing.assert_array_equal(st2.states()[r].astype(np.uint8), s_c)
