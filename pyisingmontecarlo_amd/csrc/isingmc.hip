@@ -145,6 +145,27 @@ static int dev_alloc(T **out, size_t count)
     return ISINGMC_OK;
 }
 
+// device scratch of one API call: freed on every exit path, after the stream has drained
+struct DeviceScratch {
+    hipStream_t stream;
+    std::vector<void *> ptrs;
+    explicit DeviceScratch(hipStream_t st) : stream(st) {}
+    DeviceScratch(const DeviceScratch &) = delete;
+    ~DeviceScratch()
+    {
+        if (ptrs.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    int alloc(T **out, size_t count)
+    {
+        TRY(dev_alloc(out, count));
+        ptrs.push_back(*out);
+        return ISINGMC_OK;
+    }
+};
+
 template <typename T>
 static int graph_upload(isingmc_graph *g, const T **dst, const std::vector<T> &src)
 {
@@ -763,16 +784,14 @@ static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins)
     std::vector<uint32_t> bits(g->state_words, 0u);
     for (uint64_t i = 0; i < g->nvars; i++)
         if (spins[i]) bits[g->pos[i] >> 5] |= 1u << (g->pos[i] & 31);
+    DeviceScratch scratch(s->stream);
     uint32_t *d_bits = nullptr;
-    TRY(dev_alloc(&d_bits, bits.size()));
-    hipError_t err = hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (err == hipSuccess) {
-        hipLaunchKernelGGL(pk_set_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state,
-                           g->pk.n_pos, d_bits, uint32_t(replica / 32), uint32_t(replica % 32));
-        err = hipStreamSynchronize(s->stream);
-    }
-    (void)hipFree(d_bits);
-    if (err != hipSuccess) return fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+    TRY(scratch.alloc(&d_bits, bits.size()));
+    HIP_TRY(hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pk_set_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state,
+                       g->pk.n_pos, d_bits, uint32_t(replica / 32), uint32_t(replica % 32));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
 }
 
@@ -831,9 +850,10 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
+    DeviceScratch scratch(s->stream);
     uint32_t *d_step_tabs = nullptr;
     const size_t chunk = std::min<size_t>(timesteps, 2048);
-    if (!s->has_betas) TRY(dev_alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
+    if (!s->has_betas) TRY(scratch.alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
     std::vector<uint32_t> h_tabs;
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -867,11 +887,10 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     }
     if (rc == ISINGMC_OK) {
         hipError_t err = hipGetLastError();
-        if (err == hipSuccess && (sync || d_step_tabs)) err = hipStreamSynchronize(s->stream);
+        if (err == hipSuccess && sync) err = hipStreamSynchronize(s->stream);
         if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
     }
-    if (d_step_tabs) (void)hipFree(d_step_tabs);
-    return rc;
+    return rc; // `scratch` drains the stream before it frees the step tables
 }
 
 // packed words -> one byte per spin, replica by replica
@@ -1093,20 +1112,21 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
     const bool gen_resident = !lattice && g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && !resident_disabled();
     if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
+    DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
     if (gen_resident) {
-        if (!s->has_betas) TRY(dev_alloc(&d_beta_steps, beta_stride ? chunk : 1));
-        if (energies_per_step) TRY(dev_alloc(&d_gen_energies, chunk * R));
+        if (!s->has_betas) TRY(scratch.alloc(&d_beta_steps, beta_stride ? chunk : 1));
+        if (energies_per_step) TRY(scratch.alloc(&d_gen_energies, chunk * R));
     }
     unsigned long long *d_steps = nullptr;
     LatThr *d_thr_steps = nullptr;
     std::vector<unsigned long long> h_steps;
     std::vector<LatThr> h_thr;
     if (energies_per_step && lattice) {
-        TRY(dev_alloc(&d_steps, chunk * R * 2));
+        TRY(scratch.alloc(&d_steps, chunk * R * 2));
         h_steps.resize(chunk * R * 2);
     }
-    if (resident && !s->has_betas) TRY(dev_alloc(&d_thr_steps, beta_stride ? chunk : 1));
+    if (resident && !s->has_betas) TRY(scratch.alloc(&d_thr_steps, beta_stride ? chunk : 1));
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
@@ -1200,10 +1220,6 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         if (err == hipSuccess) err = hipEventElapsedTime(device_ms, s->ev0, s->ev1);
         if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
     }
-    if (d_steps) (void)hipFree(d_steps);
-    if (d_thr_steps || d_beta_steps || d_gen_energies) (void)hipStreamSynchronize(s->stream);
-    for (void *p : {(void *)d_thr_steps, (void *)d_beta_steps, (void *)d_gen_energies})
-        if (p) (void)hipFree(p);
     if (rc != ISINGMC_OK) return rc;
     HIP_TRY(hipGetLastError());
     if (sync) HIP_TRY(hipStreamSynchronize(s->stream));
