@@ -1,0 +1,99 @@
+"""Randomised parity (hypothesis, derandomised): random graphs / lattices / parameters on the GPU against
+the oracle engines, bit for bit.  Covers ragged inputs the hand-written cases miss: duplicate edges, self
+loops, isolated sites, odd replica counts, zero-length runs, extreme betas."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+pytestmark = pytest.mark.gpu
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@st.composite
+def random_graph(draw, uniform):
+    n = draw(st.integers(2, 90))
+    m = draw(st.integers(1, 3 * n))
+    rng = np.random.default_rng(draw(st.integers(0, 2 ** 32 - 1)))
+    ea = rng.integers(0, n, m).astype(np.uint64)
+    eb = rng.integers(0, n, m).astype(np.uint64)
+    if uniform:  # one |J|, degree <= 6, no self loops needed but allowed (they only shift the energy)
+        keep, deg = [], np.zeros(n, dtype=int)
+        for k in range(m):
+            a, b = int(ea[k]), int(eb[k])
+            if a == b or (deg[a] < 6 and deg[b] < 6):
+                keep.append(k)
+                if a != b:
+                    deg[a] += 1; deg[b] += 1
+        if not any(ea[k] != eb[k] for k in keep):
+            keep = [0]; ea[0], eb[0] = 0, 1
+        ea, eb = ea[keep], eb[keep]
+        ej = rng.choice([-1.0, 1.0], len(ea)) * draw(st.sampled_from([1.0, 0.5, 2.25]))
+    else:
+        ej = np.round(rng.normal(size=m), 3)
+    nvars = int(max(ea.max(), eb.max())) + 1 + draw(st.integers(0, 3))   # trailing isolated sites
+    return ea, eb, ej, nvars
+
+
+@settings(max_examples=25, **COMMON)
+@given(g=random_graph(uniform=False), R=st.integers(1, 11), T=st.integers(0, 6),
+       beta=st.sampled_from([0.0, 0.05, 0.4, 1.3, 7.0, -0.2]), with_bias=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
+def test_random_general_graphs(capi, oracle, g, R, T, beta, with_bias, seed):
+    ea, eb, ej, nvars = g
+    biases = np.round(np.random.default_rng(seed % 2 ** 32).normal(size=nvars), 2) if with_bias else None
+    seeds = capi.make_seeds(seed, R)
+    graph = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
+    states = capi.States(graph, seeds)
+    states.do_time_steps(T, beta)
+    spins, energies = states.states(), states.energies()
+    for r in range(R):
+        e_ref, s_ref = oracle.gen_run(ea, eb, ej, nvars, seeds[r], [beta] * T, biases=biases)
+        assert np.array_equal(spins[r].astype(np.uint8), s_ref)
+        assert abs(energies[r] - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
+
+
+@settings(max_examples=25, **COMMON)
+@given(g=random_graph(uniform=True), R=st.integers(1, 70), T=st.integers(0, 5),
+       beta=st.sampled_from([0.0, 0.1, 0.5, 2.0, 30.0]), per_replica=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
+def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_replica, seed):
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    ea, eb, ej, nvars = g
+    seeds = capi.make_seeds(seed, R)
+    graph = capi.Graph(ea, eb, ej, nvars=nvars)
+    states = capi.States(graph, seeds)
+    if per_replica:
+        betas = np.linspace(0.0, 2.0, R)
+        states.set_betas(betas)
+        states.do_time_steps(T)
+        e_ref, s_ref = oracle.pk_run(ea, eb, ej, nvars, seeds, T, beta_replica=betas)
+    else:
+        states.do_time_steps(T, beta)
+        e_ref, s_ref = oracle.pk_run(ea, eb, ej, nvars, seeds, T, betas=[beta] * T)
+    assert np.array_equal(states.states().astype(np.uint8), s_ref[:R])
+    assert np.allclose(states.energies(), e_ref, rtol=1e-12, atol=1e-9)
+
+
+@settings(max_examples=20, **COMMON)
+@given(wq=st.integers(1, 6), H=st.sampled_from([2, 4, 6, 8, 12, 16, 34]), pm=st.booleans(), R=st.integers(1, 5),
+       T=st.integers(0, 5), beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0]), jabs=st.sampled_from([1.0, 0.3]),
+       seed=st.integers(0, 2 ** 64 - 1))
+def test_random_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, seed):
+    W = 64 * wq
+    if (H * wq) % 4 or H < 4:
+        H = 4 * H                                   # fast-path geometry: H * W/64 multiple of 4, H >= 4
+    ea, eb, ej = exact.square_lattice_edges(W, H, jabs if pm else -jabs, np.random.default_rng(seed % 2 ** 32) if pm else None)
+    graph = capi.Graph(ea, eb, ej)
+    assert graph.kind == capi.KIND_LATTICE2D
+    seeds = capi.make_seeds(seed, R)
+    states = capi.States(graph, seeds)
+    states.do_time_steps(T, beta)
+    if pm:
+        lat = oracle.Lat(W, H, jabs, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8))
+    else:
+        lat = oracle.Lat(W, H, jabs, 0)
+    packed = states.packed()
+    for r in range(R):
+        ref = lat.init(seeds[r])
+        for t in range(T):
+            lat.sweep(ref, seeds[r], t, beta)
+        assert np.array_equal(packed[r], ref)
