@@ -154,6 +154,15 @@ int isingmc_get_packed_states(isingmc_states *states, uint32_t *words_out);
 /* Absolute timestep counter of the replicas (Philox counter word; persists across calls). */
 uint64_t isingmc_states_timestep(const isingmc_states *states);
 
+/* replaces the whole sampling loop of lattice.rs:271-287 / classicising.rs:144-173:
+ *   thermalization x do_time_step(beta);  n_samples x { sampling_freq x do_time_step(beta);
+ *   states[r][k][:] = state_ref();  energies[r][k] = get_energy() }
+ * energies_out: double[R][n_samples]; states_out: bytes [R][n_samples][nvars] (the bool[R,S,N] array).
+ * beta is ignored while per-replica betas are set.  Sweeps, sample copies and measurements are
+ * enqueued back to back; the host waits once per chunk of samples. */
+int isingmc_run_sampling(isingmc_states *states, double beta, size_t thermalization, size_t sampling_freq,
+                         size_t n_samples, double *energies_out, uint8_t *states_out);
+
 /* ---- on-stream parallel tempering (lattice path) --------------------------------------------------
  * The classical counterpart of the loop in tempering.rs:177-194 { timesteps; parallel_tempering_step }
  * with NO host synchronisation inside it: sweeps, the energy measurement, the exchange decisions

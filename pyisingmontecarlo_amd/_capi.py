@@ -48,6 +48,7 @@ _PROTOTYPES = {
     "isingmc_get_states": (C.c_int, [_vp, _vp, C.c_size_t]),
     "isingmc_get_packed_states": (C.c_int, [_vp, _vp]),
     "isingmc_states_timestep": (C.c_uint64, [_vp]),
+    "isingmc_run_sampling": (C.c_int, [_vp, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
     "isingmc_pt_attach": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64]),
     "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "isingmc_pt_time_steps": (C.c_int, [_vp, C.c_size_t]),
@@ -257,6 +258,15 @@ class States:
         ms = C.c_float()
         _check(lib().isingmc_do_time_steps_timed(self._h, timesteps, _p(b), 0 if b.size == 1 else 1, C.byref(ms)))
         return ms.value
+
+    def run_sampling(self, beta, thermalization, sampling_freq, n_samples):
+        """(energies float64[R, S], states bool[R, S, nvars]) -- the sampling loop of lattice.rs:271-287."""
+        R, N = self.count, self.graph.nvars
+        energies = np.zeros((R, n_samples), dtype=np.float64)
+        states = np.zeros((R, n_samples, N), dtype=np.bool_)
+        _check(lib().isingmc_run_sampling(self._h, float(0.0 if beta is None else beta), thermalization, sampling_freq,
+                                          n_samples, _p(energies), states.ctypes.data_as(_vp)))
+        return energies, states
 
     def energies(self):
         out = np.zeros(self.count, dtype=np.float64)

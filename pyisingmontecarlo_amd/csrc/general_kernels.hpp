@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restric
     sm[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { se[threadIdx.x] += se[threadIdx.x + s]; sm[threadIdx.x] += sm[threadIdx.x + s]; }
+        if (int(threadIdx.x) < s) { se[threadIdx.x] += se[threadIdx.x + s]; sm[threadIdx.x] += sm[threadIdx.x + s]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) { out_e[r] = se[0]; out_m[r] = sm[0]; }

@@ -1287,6 +1287,121 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// sampling run: thermalise, then S x { freq timesteps; record state + energy }  (lattice.rs:271-287,
+// classicising.rs:144-173).  Everything is enqueued on the stream -- sweeps, a device-to-device copy of
+// the packed configurations into a sample ring, the measurement kernels -- and the host only waits once
+// per chunk of samples (<= 512 MiB of packed states), then expands the bits to bools on its threads.
+// ------------------------------------------------------------------------------------------------
+static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot)
+{
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R;
+    if (s->packed) {
+        HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(1024, g->pk.n_pos / 2048)));
+        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+            hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
+                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(R - 32 * g0));
+        }
+    } else if (g->kind == ISINGMC_KIND_LATTICE2D) {
+        HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        LAT_DISPATCH(launch_lat_measure, s, counts_slot, size_t(2));
+    } else {
+        for (size_t r0 = 0; r0 < R; r0 += MAX_GRID_Y) {
+            const size_t n = std::min(MAX_GRID_Y, R - r0);
+            const dim3 grid(s->n_partials, unsigned(n));
+            if (g->w_is_float)
+                hipLaunchKernelGGL(gen_measure_kernel<float>, grid, dim3(256), 0, s->stream, s->d_state + r0 * g->state_words,
+                                   g->gdev, s->d_pe + r0 * s->n_partials, s->d_pm + r0 * s->n_partials);
+            else
+                hipLaunchKernelGGL(gen_measure_kernel<double>, grid, dim3(256), 0, s->stream, s->d_state + r0 * g->state_words,
+                                   g->gdev, s->d_pe + r0 * s->n_partials, s->d_pm + r0 * s->n_partials);
+        }
+        hipLaunchKernelGGL(gen_reduce_kernel, dim3(unsigned(R)), dim3(256), 0, s->stream, s->d_pe, s->d_pm, s->n_partials,
+                           e_slot, m_slot);
+    }
+    HIP_TRY(hipGetLastError());
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq,
+                                    size_t n_samples, double *energies_out, uint8_t *states_out)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (sampling_freq == 0) return fail(ISINGMC_ERR_INVALID, "sampling_freq must be positive");
+    if (n_samples && s->R && (!energies_out || !states_out)) return fail(ISINGMC_ERR_INVALID, "NULL output");
+    if (!s->has_betas && !std::isfinite(beta)) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    const size_t R = s->R, S = n_samples, N = g->nvars;
+    // a uniform beta is installed as per-replica thresholds for the duration of the call: the step
+    // launches then need no per-call host tables and nothing in the loop synchronises
+    struct BetaGuard {
+        isingmc_states *s;
+        bool active;
+        ~BetaGuard() { if (active) (void)isingmc_states_set_betas(s, nullptr); }
+    } guard{s, false};
+    if (!s->has_betas && R) {
+        const std::vector<double> b(R, beta);
+        TRY(isingmc_states_set_betas(s, b.data()));
+        guard.active = true;
+    }
+    TRY(run_steps(s, thermalization, nullptr, 0, nullptr, nullptr, /*sync=*/false));
+    if (R == 0 || S == 0) {
+        if (R == 0) s->t += S * sampling_freq;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return ISINGMC_OK;
+    }
+    const bool counts = s->packed || g->kind == ISINGMC_KIND_LATTICE2D;
+    const size_t words = s->packed ? s->groups * size_t(g->pk.n_pos) : R * g->state_words;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(S, (size_t(512) << 20) / (words * sizeof(uint32_t))));
+    DeviceScratch scratch(s->stream);
+    uint32_t *d_samples = nullptr;
+    unsigned long long *d_counts = nullptr;
+    double *d_e = nullptr;
+    long long *d_m = nullptr;
+    TRY(scratch.alloc(&d_samples, chunk * words));
+    if (counts) TRY(scratch.alloc(&d_counts, chunk * R * 2));
+    else {
+        TRY(scratch.alloc(&d_e, chunk * R));
+        TRY(scratch.alloc(&d_m, chunk * R));
+    }
+    std::vector<uint32_t> h_samples(chunk * words);
+    std::vector<unsigned long long> h_counts(counts ? chunk * R * 2 : 0);
+    std::vector<double> h_e(counts ? 0 : chunk * R);
+    for (size_t k0 = 0; k0 < S; k0 += chunk) {
+        const size_t nk = std::min(chunk, S - k0);
+        for (size_t k = 0; k < nk; k++) {
+            TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
+            HIP_TRY(hipMemcpyAsync(d_samples + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+            TRY(measure_enqueue(s, counts ? d_counts + k * R * 2 : nullptr, counts ? nullptr : d_e + k * R, counts ? nullptr : d_m + k * R));
+        }
+        HIP_TRY(hipMemcpyAsync(h_samples.data(), d_samples, nk * words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        if (counts) HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        else HIP_TRY(hipMemcpyAsync(h_e.data(), d_e, nk * R * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        parallel_for(nk * R, [&](size_t idx) {
+            const size_t k = idx / R, r = idx % R;
+            uint8_t *out = states_out + (r * S + k0 + k) * N;
+            double energy;
+            if (s->packed) {
+                const uint32_t *w = h_samples.data() + k * words + (r / 32) * g->pk.n_pos;
+                const uint32_t bit = uint32_t(r % 32);
+                for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
+                energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * R + r) * 2]))) + g->self_energy;
+            } else {
+                unpack_state(g, h_samples.data() + k * words + r * g->state_words, out);
+                if (counts) energy = g->jabs * double(2 * int64_t(N) - 2 * int64_t(h_counts[(k * R + r) * 2]));
+                else energy = h_e[k * R + r] + g->self_energy;
+            }
+            energies_out[r * S + k0 + k] = energy;
+        });
+    }
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // on-stream parallel tempering (no host synchronisation inside the sweep / measure / swap loop)
 // ------------------------------------------------------------------------------------------------
 extern "C" int isingmc_states_stream(isingmc_states *s, void **stream_out)

@@ -291,17 +291,12 @@ public:
 
     Lattice clone() const { return *this; } // lattice.rs:1038-1040 (the immutable device graph is shared)
 
-    static void sample_into(isingmc_states *s, double beta, size_t therm, size_t freq, size_t S, size_t R, size_t N,
+    static void sample_into(isingmc_states *s, double beta, size_t therm, size_t freq, size_t S, size_t, size_t,
                             double *energies, uint8_t *states)
     {
-        check(isingmc_do_time_steps(s, therm, &beta, 0, nullptr)); // lattice.rs:271-273
-        std::vector<double> e(R);
-        for (size_t k = 0; k < S; k++) { // lattice.rs:274-287: freq steps, then record state + energy
-            check(isingmc_do_time_steps(s, freq, &beta, 0, nullptr));
-            check(isingmc_get_states(s, states + k * N, S * N));
-            check(isingmc_get_energies(s, e.data()));
-            for (size_t r = 0; r < R; r++) energies[r * S + k] = e[r];
-        }
+        // lattice.rs:271-287: thermalise, then S x { freq steps; record state + energy } -- one library call,
+        // enqueued end to end on the device stream
+        check(isingmc_run_sampling(s, beta, therm, freq, S, energies, states));
     }
 
 private:

@@ -331,3 +331,35 @@ def test_on_stream_tempering_two_shards_in_one_process(capi, exact):
         assert np.array_equal(p, perm) and r == rounds
     assert shards[0].pt_state()[2] == swaps                 # every rank counts the same accepted swaps
     assert np.array_equal(np.concatenate([sh.packed() for sh in shards]), full.packed())
+
+
+@pytest.mark.parametrize("kind", ["lattice", "lattice_big", "general", "packed"])
+def test_run_sampling_equals_step_by_step_loop(capi, exact, monkeypatch, kind):
+    """isingmc_run_sampling (everything enqueued, one wait per chunk) against the loop it replaces."""
+    if kind == "packed":
+        monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    if kind == "lattice":
+        ea, eb, ej = exact.square_lattice_edges(64, 16, -1.0); R = 5
+    elif kind == "lattice_big":
+        ea, eb, ej = exact.square_lattice_edges(1024, 64, 1.0, np.random.default_rng(1)); R = 3   # multi-launch path
+    elif kind == "general":
+        rng = np.random.default_rng(2)
+        ea = rng.integers(0, 80, 200).astype(np.uint64); eb = rng.integers(0, 80, 200).astype(np.uint64)
+        ej = rng.normal(size=200); R = 4
+    else:
+        ea, eb, ej = exact.cubic_lattice_edges(6, -1.0); R = 37
+    seeds = capi.make_seeds(4, R)
+    g = capi.Graph(ea, eb, ej)
+    a = capi.States(g, seeds)
+    e_a, s_a = a.run_sampling(0.45, 3, 2, 4)
+    b = capi.States(g, seeds)
+    b.do_time_steps(3, 0.45)
+    for k in range(4):
+        b.do_time_steps(2, 0.45)
+        assert np.array_equal(s_a[:, k, :], b.states())
+        np.testing.assert_allclose(e_a[:, k], b.energies(), rtol=1e-12, atol=1e-9)
+    assert a.timestep == b.timestep == 11
+    a.do_time_steps(2, 0.45); b.do_time_steps(2, 0.45)            # the temporary per-replica betas are gone again
+    assert np.array_equal(a.states(), b.states())
+    e0, s0 = a.run_sampling(0.45, 2, 3, 0)                        # no samples: thermalisation only
+    assert e0.shape == (R, 0) and a.timestep == 15
