@@ -417,7 +417,7 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
         for (size_t Q = 0; Q < nquads; Q++) {
             uint32_t planes[N_PLANES][4];
             for (uint32_t p = 0; p < N_PLANES; p++)
-                philox_seeded(seed, (uint32_t)t, (uint32_t)Q, ctr2(t, c, p), DOM_LAT_SWEEP,
+                philox_seeded(seed, (uint32_t)t, (uint32_t)Q, DOM_LAT_SWEEP, ctr2(t, c, p),
                               planes[p]);
             uint32_t resid[4];
             unsigned n_undecided = 0;
@@ -441,9 +441,8 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
                         else if (upre > hi) accept = 0;
                         else {
                             if ((n_undecided & 3) == 0)
-                                philox_seeded(seed, (uint32_t)t, (uint32_t)Q,
-                                              ctr2(t, c, N_PLANES + n_undecided / 4),
-                                              DOM_LAT_SWEEP, resid);
+                                philox_seeded(seed, (uint32_t)t, (uint32_t)Q, DOM_LAT_SWEEP,
+                                              ctr2(t, c, N_PLANES + n_undecided / 4), resid);
                             accept = resid[n_undecided & 3] < lo;
                             n_undecided++;
                         }
@@ -717,7 +716,7 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
                     uint32_t planes[N_PLANES][4], tie_words[4];
                     unsigned n_ties = 0;
                     for (uint32_t pl = 0; pl < N_PLANES; pl++)
-                        philox_seeded(key, (uint32_t)t, (uint32_t)p0, ctr2(t, 0, pl), DOM_PK_SWEEP, planes[pl]);
+                        philox_seeded(key, (uint32_t)t, (uint32_t)p0, DOM_PK_SWEEP, ctr2(t, 0, pl), planes[pl]);
                     for (int q = 0; q < 4; q++) {
                         size_t i = site_of[p0 + 64 * q];
                         if (i == (size_t)-1) continue;
@@ -741,8 +740,8 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
                                 else if (upre > hi) accept = 0;
                                 else {
                                     if ((n_ties & 3) == 0)
-                                        philox_seeded(key, (uint32_t)t, (uint32_t)p0,
-                                                      ctr2(t, 0, N_PLANES + n_ties / 4), DOM_PK_SWEEP, tie_words);
+                                        philox_seeded(key, (uint32_t)t, (uint32_t)p0, DOM_PK_SWEEP,
+                                                      ctr2(t, 0, N_PLANES + n_ties / 4), tie_words);
                                     accept = tie_words[n_ties & 3] < lo;
                                     n_ties++;
                                 }

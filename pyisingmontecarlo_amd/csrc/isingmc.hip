@@ -932,8 +932,10 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
         hipStream_t stream = s->n_lanes > 1 ? s->lanes[lane] : s->stream;
         for (size_t r0 = lo; r0 < hi; r0 += MAX_GRID_Y) {
             const size_t n = std::min(MAX_GRID_Y, hi - r0);
+            // diagnostic: ISINGMC_DEBUG_SWEEP_LDS=<bytes> of unused LDS per workgroup lowers the occupancy
+            static const unsigned dbg_lds = [] { const char *e = getenv("ISINGMC_DEBUG_SWEEP_LDS"); return e ? unsigned(atoi(e)) : 0u; }();
             const auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, stream,
+                hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), dbg_lds, stream,
                                    s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
                                    s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
             };

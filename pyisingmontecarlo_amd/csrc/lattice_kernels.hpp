@@ -105,6 +105,23 @@ struct BufPlanes {
     __device__ __forceinline__ void store1(uint32_t w, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, own_off + 4 * w, 0, 0); }
 };
 
+// side-neighbour words from the centre words and the one word beyond the quad (in n.si[0])
+__device__ __forceinline__ void side_words(QuadNbr &n, bool odd)
+{
+    const uint32_t sw = n.si[0];
+    if (odd) {
+        n.si[0] = (n.ce[0] >> 1) | (n.ce[1] << 31);
+        n.si[1] = (n.ce[1] >> 1) | (n.ce[2] << 31);
+        n.si[2] = (n.ce[2] >> 1) | (n.ce[3] << 31);
+        n.si[3] = (n.ce[3] >> 1) | (sw << 31);
+    } else {
+        n.si[3] = (n.ce[3] << 1) | (n.ce[2] >> 31);
+        n.si[2] = (n.ce[2] << 1) | (n.ce[1] >> 31);
+        n.si[1] = (n.ce[1] << 1) | (n.ce[0] >> 31);
+        n.si[0] = (n.ce[0] << 1) | (sw >> 31);
+    }
+}
+
 // Loads the 4 own words and the neighbour words of quad Q (row y, first word xw) in plane `colour`.
 template <bool VEC, bool UNI, typename Mem>
 __device__ __forceinline__ void load_quad(const Mem &mem, const LatGeom &g,
@@ -130,17 +147,8 @@ __device__ __forceinline__ void load_quad(const Mem &mem, const LatGeom &g,
         n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
         n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
         n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
-        if (odd) {
-            n.si[0] = (c4.x >> 1) | (c4.y << 31);
-            n.si[1] = (c4.y >> 1) | (c4.z << 31);
-            n.si[2] = (c4.z >> 1) | (c4.w << 31);
-            n.si[3] = (c4.w >> 1) | (sw << 31);
-        } else {
-            n.si[0] = (c4.x << 1) | (sw >> 31);
-            n.si[1] = (c4.y << 1) | (c4.x >> 31);
-            n.si[2] = (c4.z << 1) | (c4.y >> 31);
-            n.si[3] = (c4.w << 1) | (c4.z >> 31);
-        }
+        n.si[0] = sw;
+        side_words(n, odd);
 #pragma unroll
         for (int q = 0; q < 4; q++) widx[q] = w0 + q;
     } else { // narrow lattices (wpr = 1, 2, ...): the quad's words sit in different rows
@@ -188,102 +196,215 @@ __device__ __forceinline__ void bond_masks(const uint32_t own, const QuadNbr &n,
     }
 }
 
-// One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
-// plane `own_plane`, reading its neighbours from `oth_plane`.  The planes may live in HBM (sweep kernel)
-// or in LDS (resident kernel): the function only sees pointers.
-template <bool VEC, bool PMJ, bool UNI, typename Mem>
-__device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
-                                            const LatThr thr, const uint32_t *__restrict__ jn,
-                                            const uint32_t jneg_uniform, const uint32_t gid)
+// Bit-sliced decision state of one quad: class masks (3 / 4 satisfied bonds), "prefix already smaller than
+// the threshold" and "prefix still equal to it" per spin.
+struct QuadState {
+    uint32_t eq3[4], eq4[4], lt[4], und[4];
+};
+
+// the wave-uniform threshold data of a replica as the kernels consume it
+struct ThrBits {
+    uint32_t hi3, hi4; // top N_PLANES bits of T3, T4
+    uint32_t lo3, lo4; // low 32 bits
+    bool all3, all4;   // T = 2^THR_BITS: accepted outright
+    bool any_all;
+};
+
+__device__ __forceinline__ ThrBits thr_bits(const LatThr thr)
 {
-    uint32_t Q, qy, qxw;
-    thread_to_quad<UNI>(g, gid, Q, qy, qxw);
-
-    uint32_t own[4], widx[4];
-    QuadNbr n;
-    load_quad<VEC, UNI>(mem, g, colour, Q, qy, qxw, own, n, widx);
-
-    // bit-sliced count of satisfied bonds: le2 (always flips), eq3, eq4
-    uint32_t eq3[4], eq4[4], lt[4], und[4], le2[4];
+    ThrBits b;
     // thresholds have THR_BITS = N_PLANES + 32 bits: the top N_PLANES are compared bit-sliced, the
     // low 32 against one residual Philox word
-    const bool all3 = (thr.T3 >> THR_BITS) != 0, all4 = (thr.T4 >> THR_BITS) != 0;
-    const uint32_t hi3 = uint32_t(thr.T3 >> 32) & ((1u << N_PLANES) - 1), hi4 = uint32_t(thr.T4 >> 32) & ((1u << N_PLANES) - 1);
+    b.all3 = (uint32_t(thr.T3 >> 32) >> N_PLANES) != 0;
+    b.all4 = (uint32_t(thr.T4 >> 32) >> N_PLANES) != 0;
+    b.any_all = __builtin_amdgcn_readfirstlane(uint32_t(b.all3 | b.all4)) != 0; // wave-uniform: thr is per replica
+    b.hi3 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T3 >> 32) & ((1u << N_PLANES) - 1));
+    b.hi4 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T4 >> 32) & ((1u << N_PLANES) - 1));
+    b.lo3 = uint32_t(thr.T3);
+    b.lo4 = uint32_t(thr.T4);
+    return b;
+}
+
+// bit-sliced count of satisfied bonds -> class masks of the 128 spins of a quad
+// +-J: the 16 sign words of quad Q (4 directions x 4 words), loaded in one batch BEFORE the spin words so
+// that one wait covers both (behind a branch per word they were four dependent round trips to L2)
+struct QuadSigns {
+    uint32_t w[4][4]; // [word][direction: up, down, centre, side]
+};
+
+template <bool PMJ>
+__device__ __forceinline__ void load_signs(const uint32_t *__restrict__ jn, const LatGeom &g, const uint32_t Q, QuadSigns &js)
+{
+    if constexpr (PMJ) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) { // wpp is a multiple of 4 (fast-path condition): every quad is 16-byte aligned
+            const uint4 v = *reinterpret_cast<const uint4 *>(jn + size_t(d) * g.wpp + 4 * size_t(Q));
+            js.w[0][d] = v.x; js.w[1][d] = v.y; js.w[2][d] = v.z; js.w[3][d] = v.w;
+        }
+    }
+}
+
+template <bool PMJ>
+__device__ __forceinline__ void quad_classes(const uint32_t own[4], const QuadNbr &n, const uint32_t widx[4], const LatGeom &g,
+                                             const ThrBits &tb, const QuadSigns &js, const uint32_t jneg_uniform,
+                                             QuadState &st)
+{
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t a0, a1, a2, a3;
-        bond_masks<PMJ>(own[q], n, q, jn, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+        if constexpr (PMJ) { // jneg planes hold 1 where J < 0: satisfied = own ^ neighbour ^ jneg
+            a0 = own[q] ^ n.up[q] ^ js.w[q][0];
+            a1 = own[q] ^ n.dn[q] ^ js.w[q][1];
+            a2 = own[q] ^ n.ce[q] ^ js.w[q][2];
+            a3 = own[q] ^ n.si[q] ^ js.w[q][3];
+        } else {
+            bond_masks<false>(own[q], n, q, nullptr, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+        }
         const uint32_t s01 = a0 ^ a1, c01 = a0 & a1, s23 = a2 ^ a3, c23 = a2 & a3;
-        eq4[q] = c01 & c23;
-        eq3[q] = (c01 & s23) | (c23 & s01);
+        st.eq4[q] = c01 & c23;
+        st.eq3[q] = __builtin_amdgcn_bitop3_b32(c01, s23, c23 & s01, 0xEA); // (c01 & s23) | (c23 & s01)
         // pin the two class masks in registers: hipcc otherwise re-derives them from the bond masks inside
         // every plane (7 instead of 5 instructions per word and plane)
-        asm("" : "+v"(eq3[q]), "+v"(eq4[q]));
-        le2[q] = ~(eq3[q] | eq4[q]);
-        lt[q] = (all3 ? eq3[q] : 0u) | (all4 ? eq4[q] : 0u); // threshold 2^THR_BITS: accepted outright
-        und[q] = (eq3[q] | eq4[q]) & ~lt[q];
+        asm("" : "+v"(st.eq3[q]), "+v"(st.eq4[q]));
     }
-
-    // N_PLANES bit-planes of the uniform prefixes, MSB first; per spin the threshold bit of its class
-    // counter = (t_lo, quad, ctr2, domain): the lane-varying quad index sits in a NON-multiplied word, which
-    // keeps round 1 of every call on the scalar unit and rounds 2-3 at one vector multiply (16 instead of 18)
-    const uint32_t c0 = uint32_t(t), c1 = Q;
+    if (tb.any_all) { // threshold 2^THR_BITS (beta = 0 ...): accepted outright; scalar branch, rarely taken
 #pragma unroll
-    for (int p = 0; p < N_PLANES; p++) {
-        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, p), DOM_LAT_SWEEP), key);
-        const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-        // threshold bit of this plane for class 3 / class 4: wave-uniform, so the per-spin threshold word is
-        // one of {0, eq3, eq4, eq3|eq4} -- a scalar branch picks the register, 3 instructions per word remain
-        const uint32_t sel = __builtin_amdgcn_readfirstlane(((hi3 >> (N_PLANES - 1 - p)) & 1u) | (((hi4 >> (N_PLANES - 1 - p)) & 1u) << 1));
-        auto step = [&](int q, uint32_t tb) {
-            const uint32_t decided = und[q] & (rr[q] ^ tb); // random bit differs from threshold bit
-            lt[q] |= decided & tb;                          // ... and it is the smaller one
-            und[q] ^= decided;
-        };
-        if (sel == 0) {
+        for (int q = 0; q < 4; q++) {
+            st.lt[q] = (tb.all3 ? st.eq3[q] : 0u) | (tb.all4 ? st.eq4[q] : 0u);
+            st.und[q] = (st.eq3[q] | st.eq4[q]) & ~st.lt[q];
+        }
+    } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) und[q] &= ~rr[q];
-        } else if (sel == 1) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) step(q, eq3[q]);
-        } else if (sel == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) step(q, eq4[q]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) step(q, eq3[q] | eq4[q]);
+        for (int q = 0; q < 4; q++) {
+            st.lt[q] = 0;
+            st.und[q] = st.eq3[q] | st.eq4[q];
         }
     }
+}
 
-    // residual stage: spins whose prefix equals the threshold's top bits (ties) draw 32 more bits
-    uint32_t acc[4];
+// N_PLANES bit-planes of the uniform prefixes, MSB first, compared against the threshold bit of each spin's
+// class, for NQ quads at once.  Philox counter = (t_lo, quad, domain, ctr2): the lane-varying quad index sits
+// in a NON-multiplied word, which keeps round 1 of every call on the scalar unit and rounds 2-3 at one vector
+// multiply each; the call index sits in the OTHER non-multiplied word, so those two vector multiplies do not
+// depend on it and are shared by all calls of a quad (common subexpressions): 2 + 14 per call instead of 16.
+// NQ > 1 decides several quads together (the wave-uniform work is then issued once); measured, a two-quad
+// kernel built on it ran exactly as fast as the one-quad kernel (the kernel is bound by VALU cycles, which
+// are the same per quad, and the scalar unit runs beside it), so only NQ = 1 is instantiated.
+template <int NQ>
+__device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t (&Q)[NQ], const uint32_t colour, const uint64_t t,
+                                            const uint2 key, const PhiloxVKeys &vk, const ThrBits &tb)
+{
+    const uint32_t c0 = uint32_t(t);
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = le2[q] | lt[q];
+    for (int p = 0; p < N_PLANES; p++) {
+        uint32_t rr[NQ][4];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const uint4 rnd = philox4x32_10(make_uint4(c0, Q[j], DOM_LAT_SWEEP, ctr2(t, colour, p)), key, vk);
+            rr[j][0] = rnd.x; rr[j][1] = rnd.y; rr[j][2] = rnd.z; rr[j][3] = rnd.w;
+        }
+        // threshold bit of this plane for class 3 / class 4: wave-uniform, so the per-spin threshold word is
+        // one of {0, eq3, eq4, eq3|eq4} -- scalar branches pick the register.
+        // decided = und & (r ^ tb): the random bit differs from the threshold bit; it is the smaller one where
+        // tb = 1.  Three full-rate instructions per word: v_bitop3 (und & ~r & tb, table 0x20), v_or, v_bitop3
+        // (und & ~(r ^ tb), table 0x90); hipcc's own selection uses v_and_or_b32, which issues at half rate
+        auto step = [&](int j, int q, uint32_t tbw) {
+            const uint32_t smaller = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x20); // und & ~r & tb
+            st[j].lt[q] |= smaller;
+            st[j].und[q] = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x90);
+        };
+        const bool b3 = (tb.hi3 >> (N_PLANES - 1 - p)) & 1u, b4 = (tb.hi4 >> (N_PLANES - 1 - p)) & 1u;
+        if (b3) {
+            if (b4) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q] | st[j].eq4[q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NQ; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q]);
+            }
+        } else if (b4) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) step(j, q, st[j].eq4[q]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NQ; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) st[j].und[q] &= ~rr[j][q];
+        }
+    }
+}
+
+// residual stage: spins whose prefix equals the threshold's top bits (ties) draw 32 more bits; acc = flips
+__device__ __forceinline__ void quad_ties(const QuadState &st, const uint32_t Q, const uint32_t colour, const uint64_t t,
+                                          const uint2 key, const PhiloxVKeys &vk, const ThrBits &tb, uint32_t acc[4])
+{
+    const uint32_t c0 = uint32_t(t), c1 = Q;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_bitop3_b32(st.eq3[q], st.eq4[q], st.lt[q], 0xAB); // ~(eq3|eq4) | lt
 #ifdef ISINGMC_TIMING_ONLY_NO_TIES // diagnostic build: what the tie stage costs (results are wrong without it)
     if (false) {
 #else
-    if (und[0] | und[1] | und[2] | und[3]) {
+    if (st.und[0] | st.und[1] | st.und[2] | st.und[3]) {
 #endif
-        const uint32_t lo3 = uint32_t(thr.T3), lo4 = uint32_t(thr.T4);
         uint32_t nres = 0;
         // the first residual call is hoisted: inside the divergent per-word loops below it would be
         // issued once per loop (up to 4x per wave) instead of once
-        uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, colour, N_PLANES), DOM_LAT_SWEEP), key);
+        uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t m = und[q];
+            uint32_t m = st.und[q];
             while (m) {
                 const uint32_t b = __ffs(m) - 1;
                 m &= m - 1;
                 if (nres != 0 && (nres & 3u) == 0) // 5th, 9th, ... tie of this quad: rare
                     rnd = philox4x32_10(
-                        make_uint4(c0, c1, ctr2(t, colour, N_PLANES + (nres >> 2)), DOM_LAT_SWEEP), key);
-                const uint32_t lo = ((eq4[q] >> b) & 1u) ? lo4 : lo3;
+                        make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
+                const uint32_t lo = ((st.eq4[q] >> b) & 1u) ? tb.lo4 : tb.lo3;
                 if (sel4(rnd, nres & 3u) < lo) acc[q] |= 1u << b;
                 nres++;
             }
         }
     }
+}
+
+// The 128 flip decisions of quad Q from its loaded words: acc[q] bit b = 1 where the spin flips.
+template <bool PMJ>
+__device__ __forceinline__ void quad_flips(const uint32_t own[4], const QuadNbr &n, const uint32_t widx[4], const LatGeom &g,
+                                           const uint32_t colour, const uint64_t t, const uint2 key, const PhiloxVKeys &vk,
+                                           const LatThr thr, const QuadSigns &js, const uint32_t jneg_uniform,
+                                           const uint32_t Q, uint32_t acc[4])
+{
+    const ThrBits tb = thr_bits(thr);
+    QuadState st[1];
+    const uint32_t Qs[1] = {Q};
+    quad_classes<PMJ>(own, n, widx, g, tb, js, jneg_uniform, st[0]);
+    quad_planes<1>(st, Qs, colour, t, key, vk, tb);
+    quad_ties(st[0], Q, colour, t, key, vk, tb, acc);
+}
+
+// One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
+// plane `own_plane`, reading its neighbours from `oth_plane`.  The planes may live in HBM (sweep kernel)
+// or in LDS (resident kernel): the function only sees pointers.
+template <bool VEC, bool PMJ, bool UNI, typename Mem>
+__device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
+                                            const PhiloxVKeys &vk, const LatThr thr, const uint32_t *__restrict__ jn,
+                                            const uint32_t jneg_uniform, const uint32_t gid)
+{
+    uint32_t Q, qy, qxw;
+    thread_to_quad<UNI>(g, gid, Q, qy, qxw);
+
+    uint32_t own[4], widx[4], acc[4];
+    QuadNbr n;
+    QuadSigns js;
+    load_signs<PMJ>(jn, g, Q, js);
+    load_quad<VEC, UNI>(mem, g, colour, Q, qy, qxw, own, n, widx);
+    quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
 
     if constexpr (VEC) {
         mem.store4(widx[0], make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]));
@@ -306,7 +427,8 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
     mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
     mem.own_off = colour * g.wpp * 4u;
     mem.oth_off = (1 - colour) * g.wpp * 4u;
-    update_quad<VEC, PMJ, UNI>(mem, g, colour, t, keys[r], thr_replica ? thr_replica[r] : thr_uniform,
+    const uint2 key = keys[r];
+    update_quad<VEC, PMJ, UNI>(mem, g, colour, t, key, philox_vkeys(key), thr_replica ? thr_replica[r] : thr_uniform,
                                PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid);
 }
 
@@ -396,13 +518,14 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
     for (uint32_t i = tid; i < g.wpp / 2; i += nthreads) // 2*wpp words = wpp/2 uint4
         reinterpret_cast<uint4 *>(planes)[i] = reinterpret_cast<const uint4 *>(mine)[i];
     const uint2 key = keys[r];
+    const PhiloxVKeys vk = philox_vkeys(key);
     __syncthreads();
     for (uint32_t k = 0; k < timesteps; k++) {
         const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
         for (uint32_t colour = 0; colour < 2; colour++) {
             for (uint32_t gid = tid; gid < g.nquads; gid += nthreads)
                 update_quad<VEC, PMJ, false>(PtrPlanes{planes + colour * g.wpp, planes + (1 - colour) * g.wpp}, g, colour, t0 + k,
-                                             key, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform,
+                                             key, vk, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform,
                                              gid);
             __syncthreads();
         }

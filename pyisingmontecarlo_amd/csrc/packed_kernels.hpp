@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
     const uint32_t c0 = uint32_t(t), c1 = PQ;
 #pragma unroll
     for (int pl = 0; pl < N_PLANES; pl++) {
-        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, pl), DOM_PK_SWEEP), key);
+        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_PK_SWEEP, ctr2(t, 0, pl)), key);
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
         uint32_t t_odd[3], t_even[3]; // wave-uniform threshold bit-planes of the six classes
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
     for (int q = 0; q < 4; q++) acc[q] = always[q] | lt[q];
     if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
         uint32_t nres = 0;
-        uint4 rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, N_PLANES), DOM_PK_SWEEP), key);
+        uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES)), key);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t mm = und[q];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
                 const uint32_t b = __ffs(mm) - 1;
                 mm &= mm - 1;
                 if (nres != 0 && (nres & 3u) == 0)
-                    rnd = philox4x32_10(make_uint4(c0, c1, ctr2(t, 0, N_PLANES + (nres >> 2)), DOM_PK_SWEEP), key);
+                    rnd = philox4x32_10(make_uint4(c0, c1, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES + (nres >> 2))), key);
                 const uint32_t j = ((eq[q][0] >> b) & 1u) ? 0u : ((eq[q][1] >> b) & 1u) ? 1u : 2u;
                 const uint32_t row = 2 * j + 1 - (odd[q] & 1u);
                 if (sel4(rnd, nres & 3u) < tab[PK_TAB_LO + row * 32 + b]) acc[q] |= 1u << b;

@@ -36,11 +36,59 @@ __device__ __forceinline__ void philox_round(uint4 &c, uint2 &k)
 // varies and the xors are v_bitop3.
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
 {
+#ifdef ISINGMC_TIMING_ONLY_CHEAP_RNG // diagnostic build: what everything except Philox costs (results are wrong)
+    return make_uint4(c.x ^ k.x ^ c.y, c.y * 3u + c.w, c.z ^ k.y ^ (c.y >> 3), c.w + c.y);
+#endif
     philox_round<false>(c, k);
     philox_round<false>(c, k);
     philox_round<false>(c, k);
 #pragma unroll
     for (int r = 3; r < 10; r++) philox_round<true>(c, k);
+    return c;
+}
+
+// The round keys of rounds 4-10 in VECTOR registers.  Measured on gfx950 (tools/ubench/valu_forms.hip): a VALU
+// instruction with an SGPR source issues in 4.3 cycles per wave, the same instruction on VGPRs only in 2.5
+// (v_xor, v_and, v_add, v_bitop3, shifts; everything else -- multiplies, v_and_or, v_alignbit, v_cndmask -- is
+// 4.2 either way).  The xor3 of a Philox round has the (wave-uniform) round key as one source: 14 per call.
+// Holding those 14 keys in VGPRs, written once per thread, takes 26 cycles off every call (150 -> 124).
+// The v_mov is inline asm so that the compiler cannot fold the SGPR back into the uses.
+struct PhiloxVKeys {
+    uint32_t kx[7], ky[7];
+};
+
+__device__ __forceinline__ PhiloxVKeys philox_vkeys(uint2 k)
+{
+    PhiloxVKeys v;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint32_t x = k.x + uint32_t(r + 3) * 0x9E3779B9u, y = k.y + uint32_t(r + 3) * 0xBB67AE85u;
+#ifdef ISINGMC_AB_SCALAR_KEYS // A/B build: the keys stay SGPR operands
+        v.kx[r] = x;
+        v.ky[r] = y;
+#else
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v.kx[r]) : "s"(x));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v.ky[r]) : "s"(y));
+#endif
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k, const PhiloxVKeys &vk)
+{
+#ifdef ISINGMC_TIMING_ONLY_CHEAP_RNG
+    return make_uint4(c.x ^ k.x ^ c.y, c.y * 3u + c.w, c.z ^ k.y ^ (c.y >> 3), c.w + c.y);
+#endif
+    philox_round<false>(c, k);
+    philox_round<false>(c, k);
+    philox_round<false>(c, k);
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c.x;
+        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c.z;
+        c = make_uint4(__builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c.y, vk.kx[r], 0x96), uint32_t(p1),
+                       __builtin_amdgcn_bitop3_b32(uint32_t(p0 >> 32), c.w, vk.ky[r], 0x96), uint32_t(p0));
+    }
     return c;
 }
 

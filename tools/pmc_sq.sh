@@ -1,0 +1,26 @@
+#!/bin/bash
+# SQ counter passes for the sweep kernel (per-launch means printed as JSON)
+set -uo pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/pmc_sq_$1; shift
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/p$i.log" 2>&1
+  echo "pass $i done"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, json, os, sys
+from collections import defaultdict
+acc = defaultdict(list)
+for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "lat_sweep" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(json.dumps({k: sum(v) / len(v) for k, v in sorted(acc.items())}, indent=1))
+PY
