@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one "
+                         "GPU to rehearse the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,10 +85,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     from pyisingmontecarlo_amd import _capi
 
@@ -95,7 +102,7 @@ def main():
     # seeds are keyed by GLOBAL replica id: rank r owns experiments [r*R, (r+1)*R) of world*R
     seeds = _capi.make_seeds(SEED_GEN, world * R)[rank * R:(rank + 1) * R]
     t_ingest = time.perf_counter()
-    graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=local_rank)
+    graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=device)
     assert graph.kind == _capi.KIND_LATTICE2D
     states = _capi.States(graph, seeds)
     t_ingest = time.perf_counter() - t_ingest
@@ -112,7 +119,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
 
-    stats = torch.tensor([wall, device_ms], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([wall, device_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     wall, device_ms = float(stats[0]), float(stats[1])
