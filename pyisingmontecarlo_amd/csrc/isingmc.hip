@@ -729,6 +729,8 @@ static bool env_flag(const char *name)
 static bool choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return false;
+    // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
+    if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return false;
     if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0;
     return n_replicas >= 16 && g->state_words * sizeof(uint32_t) > GEN_RESIDENT_MAX_BYTES;
 }

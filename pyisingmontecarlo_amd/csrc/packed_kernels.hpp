@@ -40,16 +40,11 @@ struct PkGraphDev {
     uint32_t n_pos;             // multiple of 256
 };
 
-// satisfied-bond count of the 32 replicas at position p, bit-sliced (c0 = LSB).  Fixed trip count with
-// predication: the slot loads and then the state gathers of all neighbours are issued back to back.
-__device__ __forceinline__ void pk_count(const PkGraphDev &G, const uint32_t *__restrict__ st, uint32_t p, uint32_t s,
+// satisfied-bond count of the 32 replicas at one position, bit-sliced (c0 = LSB), from its ELL slots x[] and the
+// gathered neighbour words n[].  Fixed trip count with predication.
+__device__ __forceinline__ void pk_count(const uint32_t x[PK_MAX_DEG], const uint32_t n[PK_MAX_DEG], uint32_t s,
                                          uint32_t &deg, uint32_t &c0, uint32_t &c1, uint32_t &c2)
 {
-    uint32_t x[PK_MAX_DEG], n[PK_MAX_DEG];
-#pragma unroll
-    for (int i = 0; i < PK_MAX_DEG; i++) x[i] = G.nbr_ell[size_t(i) * G.n_pos + p];
-#pragma unroll
-    for (int i = 0; i < PK_MAX_DEG; i++) n[i] = st[x[i] == PK_NO_NBR ? p : (x[i] & 0x7FFFFFFFu)];
     c0 = c1 = c2 = deg = 0;
 #pragma unroll
     for (int i = 0; i < PK_MAX_DEG; i++) {
@@ -85,17 +80,37 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
     const uint2 key = group_keys[g];
     const uint32_t PQ = p0; // Philox counter word of the quad
 
+    // Memory phase, batched: the 4 own words and the 24 ELL slots of the quad go out together, then the 24
+    // neighbour gathers -- two round trips per thread (word by word it was eight, and the kernel ran at a third
+    // of its vector-ALU bound).  Buffer loads: descriptors in SGPRs, 32-bit offsets, data lands in the
+    // register that held the offset.
+    const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
+    uint32_t own[4], x[4][PK_MAX_DEG], nb[4][PK_MAX_DEG];
+#pragma unroll
+    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+#pragma unroll
+    for (int i = 0; i < PK_MAX_DEG; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            x[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0);
+#pragma unroll
+    for (int i = 0; i < PK_MAX_DEG; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(
+                st_rsrc, 4 * (x[q][i] == PK_NO_NBR ? p0 + 64 * q : (x[q][i] & 0x7FFFFFFFu)), 0, 0);
+
     // the (up to) three costly classes of a site: m_j = 2j + 2 - (deg & 1), k_j = deg/2 + 1 + j, i.e. table
     // row 2j for odd degrees and 2j+1 for even ones.  The table is uniform per workgroup (scalar loads);
     // the per-lane part is only the parity select.  Padding positions have degree 0 and flip freely:
     // nothing reads them.
-    uint32_t own[4], eq[4][3], odd[4], lt[4], und[4], always[4];
+    uint32_t eq[4][3], odd[4], lt[4], und[4], always[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t p = p0 + 64 * q;
-        own[q] = st[p];
         uint32_t deg, c0, c1, c2;
-        pk_count(G, st, p, own[q], deg, c0, c1, c2);
+        pk_count(x[q], nb[q], own[q], deg, c0, c1, c2);
         odd[q] = 0u - (deg & 1u);
         uint32_t costly = 0;
         lt[q] = 0;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) st[p0 + 64 * q] = own[q] ^ acc[q];
+    for (int q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(own[q] ^ acc[q], st_rsrc, 4 * (p0 + 64 * q), 0, 0);
 }
 
 // random start: position p is word q = (p & 255) >> 6 of its quad (leader p - 64 q):
