@@ -352,22 +352,46 @@ __device__ __forceinline__ void quad_ties(const QuadState &st, const uint32_t Q,
 #else
     if (st.und[0] | st.und[1] | st.und[2] | st.und[3]) {
 #endif
-        uint32_t nres = 0;
         // the first residual call is hoisted: inside the divergent per-word loops below it would be
         // issued once per loop (up to 4x per wave) instead of once
-        uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+        const uint32_t n_ties = __popc(st.und[0]) + __popc(st.und[1]) + __popc(st.und[2]) + __popc(st.und[3]);
+        if (n_ties <= 4) {
+            // all but ~0.1 % of the quads: the ties consume the four words of this one call in order.  The words
+            // rotate through r0 (three full-rate moves per tie) instead of being selected by a lane-varying
+            // index, and no loop iteration tests for a refill
+            uint32_t r0 = rnd.x, r1 = rnd.y, r2 = rnd.z, r3 = rnd.w;
+            // the two residual thresholds in VGPRs, once: v_cndmask takes its mask from the constant bus, so
+            // the compiler would otherwise re-materialise both scalars in front of every select
+            uint32_t lo3v, lo4v;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lo3v) : "s"(tb.lo3));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lo4v) : "s"(tb.lo4));
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t m = st.und[q];
-            while (m) {
-                const uint32_t b = __ffs(m) - 1;
-                m &= m - 1;
-                if (nres != 0 && (nres & 3u) == 0) // 5th, 9th, ... tie of this quad: rare
-                    rnd = philox4x32_10(
-                        make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
-                const uint32_t lo = ((st.eq4[q] >> b) & 1u) ? tb.lo4 : tb.lo3;
-                if (sel4(rnd, nres & 3u) < lo) acc[q] |= 1u << b;
-                nres++;
+            for (int q = 0; q < 4; q++) {
+                uint32_t m = st.und[q];
+                while (m) {
+                    const uint32_t bit = m & (0u - m);
+                    m ^= bit;
+                    const uint32_t lo = (bit & st.eq4[q]) ? lo4v : lo3v;
+                    if (r0 < lo) acc[q] |= bit;
+                    r0 = r1; r1 = r2; r2 = r3;
+                }
+            }
+        } else { // 5 or more ties in one quad: further calls, word n%4 of call N_PLANES + n/4
+            uint32_t nres = 0;
+            uint4 w = rnd;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t m = st.und[q];
+                while (m) {
+                    const uint32_t b = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (nres != 0 && (nres & 3u) == 0)
+                        w = philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
+                    const uint32_t lo = ((st.eq4[q] >> b) & 1u) ? tb.lo4 : tb.lo3;
+                    if (sel4(w, nres & 3u) < lo) acc[q] |= 1u << b;
+                    nres++;
+                }
             }
         }
     }
