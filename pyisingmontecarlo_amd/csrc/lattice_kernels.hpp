@@ -267,26 +267,30 @@ __device__ __forceinline__ void quad_classes(const uint32_t own[4], const QuadNb
         // every plane (7 instead of 5 instructions per word and plane)
         asm("" : "+v"(st.eq3[q]), "+v"(st.eq4[q]));
     }
-    if (tb.any_all) { // threshold 2^THR_BITS (beta = 0 ...): accepted outright; scalar branch, rarely taken
+    if (tb.any_all) { // threshold 2^THR_BITS (beta = 0 ...): the class flips outright, like k <= 2; scalar branch, rarely taken
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            st.lt[q] = (tb.all3 ? st.eq3[q] : 0u) | (tb.all4 ? st.eq4[q] : 0u);
-            st.und[q] = (st.eq3[q] | st.eq4[q]) & ~st.lt[q];
+            if (tb.all3) st.eq3[q] = 0;
+            if (tb.all4) st.eq4[q] = 0;
         }
-    } else {
+    }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            st.lt[q] = 0;
-            st.und[q] = st.eq3[q] | st.eq4[q];
-        }
+    for (int q = 0; q < 4; q++) {
+        st.lt[q] = 0;
+        st.und[q] = st.eq3[q] | st.eq4[q];
     }
 }
 
-// N_PLANES bit-planes of the uniform prefixes, MSB first, compared against the threshold bit of each spin's
-// class, for NQ quads at once.  Philox counter = (t_lo, quad, domain, ctr2): the lane-varying quad index sits
-// in a NON-multiplied word, which keeps round 1 of every call on the scalar unit and rounds 2-3 at one vector
-// multiply each; the call index sits in the OTHER non-multiplied word, so those two vector multiplies do not
-// depend on it and are shared by all calls of a quad (common subexpressions): 2 + 14 per call instead of 16.
+// N_PLANES bit-planes of the uniform prefixes compared against the top N_PLANES threshold bits of each spin's
+// class, for NQ quads at once: afterwards lt = "prefix < threshold bits", und = "prefix == threshold bits" (a tie).
+// Philox counter = (t_lo, quad, domain, ctr2): the lane-varying quad index sits in a NON-multiplied word, which
+// keeps round 1 of every call on the scalar unit and rounds 2-3 at one vector multiply each; the call index
+// sits in the OTHER non-multiplied word, so those two vector multiplies do not depend on it and are shared by
+// all calls of a quad (common subexpressions): 2 + 14 per call instead of 16.
+// The comparison runs from the LEAST significant plane up: with r the random bit and tb the threshold bit of a
+// spin, lt' = (~r & tb) | (~(r ^ tb) & lt) and eq' = eq & ~(r ^ tb) are both 3-input functions -- two
+// v_bitop3_b32 per word and plane whatever the threshold bits (MSB first needs three, and a fourth register
+// copy on the planes whose threshold bits are both 0).  Plane p is Philox call p either way: same decisions.
 // NQ > 1 decides several quads together (the wave-uniform work is then issued once); measured, a two-quad
 // kernel built on it ran exactly as fast as the one-quad kernel (the kernel is bound by VALU cycles, which
 // are the same per quad, and the scalar unit runs beside it), so only NQ = 1 is instantiated.
@@ -296,7 +300,7 @@ __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t 
 {
     const uint32_t c0 = uint32_t(t);
 #pragma unroll
-    for (int p = 0; p < N_PLANES; p++) {
+    for (int p = N_PLANES - 1; p >= 0; p--) {
         uint32_t rr[NQ][4];
 #pragma unroll
         for (int j = 0; j < NQ; j++) {
@@ -304,14 +308,10 @@ __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t 
             rr[j][0] = rnd.x; rr[j][1] = rnd.y; rr[j][2] = rnd.z; rr[j][3] = rnd.w;
         }
         // threshold bit of this plane for class 3 / class 4: wave-uniform, so the per-spin threshold word is
-        // one of {0, eq3, eq4, eq3|eq4} -- scalar branches pick the register.
-        // decided = und & (r ^ tb): the random bit differs from the threshold bit; it is the smaller one where
-        // tb = 1.  Three full-rate instructions per word: v_bitop3 (und & ~r & tb, table 0x20), v_or, v_bitop3
-        // (und & ~(r ^ tb), table 0x90); hipcc's own selection uses v_and_or_b32, which issues at half rate
+        // one of {0, eq3, eq4, eq3|eq4} -- scalar branches pick the register
         auto step = [&](int j, int q, uint32_t tbw) {
-            const uint32_t smaller = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x20); // und & ~r & tb
-            st[j].lt[q] |= smaller;
-            st[j].und[q] = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x90);
+            st[j].lt[q] = __builtin_amdgcn_bitop3_b32(rr[j][q], tbw, st[j].lt[q], 0x8E);   // (~r & tb) | (~(r ^ tb) & lt)
+            st[j].und[q] = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x90); // eq & ~(r ^ tb)
         };
         const bool b3 = (tb.hi3 >> (N_PLANES - 1 - p)) & 1u, b4 = (tb.hi4 >> (N_PLANES - 1 - p)) & 1u;
         if (b3) {
@@ -335,7 +335,10 @@ __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t 
 #pragma unroll
             for (int j = 0; j < NQ; j++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) st[j].und[q] &= ~rr[j][q];
+                for (int q = 0; q < 4; q++) {
+                    st[j].lt[q] &= ~rr[j][q];
+                    st[j].und[q] &= ~rr[j][q];
+                }
         }
     }
 }
