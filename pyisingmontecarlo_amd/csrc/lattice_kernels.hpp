@@ -215,11 +215,15 @@ __device__ __forceinline__ ThrBits thr_bits(const LatThr thr)
     ThrBits b;
     // thresholds have THR_BITS = N_PLANES + 32 bits: the top N_PLANES are compared bit-sliced, the
     // low 32 against one residual Philox word
-    b.all3 = (uint32_t(thr.T3 >> 32) >> N_PLANES) != 0;
-    b.all4 = (uint32_t(thr.T4 >> 32) >> N_PLANES) != 0;
-    b.any_all = __builtin_amdgcn_readfirstlane(uint32_t(b.all3 | b.all4)) != 0; // wave-uniform: thr is per replica
-    b.hi3 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T3 >> 32) & ((1u << N_PLANES) - 1));
-    b.hi4 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T4 >> 32) & ((1u << N_PLANES) - 1));
+    // the high words go through readfirstlane first: thr is per replica (wave-uniform), and without it the
+    // compiler fuses the tests below into 64-bit compares, which exist only on the vector unit
+    const uint32_t h3 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T3 >> 32));
+    const uint32_t h4 = __builtin_amdgcn_readfirstlane(uint32_t(thr.T4 >> 32));
+    b.all3 = (h3 >> N_PLANES) != 0;
+    b.all4 = (h4 >> N_PLANES) != 0;
+    b.any_all = ((h3 | h4) >> N_PLANES) != 0;
+    b.hi3 = h3 & ((1u << N_PLANES) - 1);
+    b.hi4 = h4 & ((1u << N_PLANES) - 1);
     b.lo3 = uint32_t(thr.T3);
     b.lo4 = uint32_t(thr.T4);
     return b;
@@ -313,20 +317,20 @@ __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t 
             st[j].lt[q] = __builtin_amdgcn_bitop3_b32(rr[j][q], tbw, st[j].lt[q], 0x8E);   // (~r & tb) | (~(r ^ tb) & lt)
             st[j].und[q] = __builtin_amdgcn_bitop3_b32(st[j].und[q], rr[j][q], tbw, 0x90); // eq & ~(r ^ tb)
         };
-        const bool b3 = (tb.hi3 >> (N_PLANES - 1 - p)) & 1u, b4 = (tb.hi4 >> (N_PLANES - 1 - p)) & 1u;
-        if (b3) {
-            if (b4) {
+        // one scalar selector per plane (the scalar unit runs beside the vector ALU; as two nested bool tests the
+        // compiler parked the second bool in a VGPR: a v_cndmask and a v_cmp per plane)
+        const uint32_t sel = __builtin_amdgcn_readfirstlane(((tb.hi3 >> (N_PLANES - 1 - p)) & 1u) | (((tb.hi4 >> (N_PLANES - 1 - p)) & 1u) << 1));
+        if (sel == 3) {
 #pragma unroll
-                for (int j = 0; j < NQ; j++)
+            for (int j = 0; j < NQ; j++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q] | st[j].eq4[q]);
-            } else {
+                for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q] | st[j].eq4[q]);
+        } else if (sel == 1) {
 #pragma unroll
-                for (int j = 0; j < NQ; j++)
+            for (int j = 0; j < NQ; j++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q]);
-            }
-        } else if (b4) {
+                for (int q = 0; q < 4; q++) step(j, q, st[j].eq3[q]);
+        } else if (sel == 2) {
 #pragma unroll
             for (int j = 0; j < NQ; j++)
 #pragma unroll
