@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
     uint32_t acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = always[q] | lt[q];
+#ifdef ISINGMC_TIMING_ONLY_NO_TIES // diagnostic build: what the tie stage costs (results are wrong without it)
+    if (false) {
+#else
     if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
+#endif
         uint32_t nres = 0;
         uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES)), key);
 #pragma unroll
