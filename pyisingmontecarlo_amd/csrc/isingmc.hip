@@ -941,7 +941,22 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
                                    s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
                                    s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
             };
-            if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
+            // large uniform-J launches: every thread loops over two quads (measured: 2 quads +4 %, 4 +2.7 %, 8 +1.3 %;
+            // the +-J kernel needs 66 VGPRs in the loop form -- 7 waves per SIMD -- and loses 2 %).
+            // ISINGMC_SWEEP_ITERS=1|2|4|8 forces the choice (measurement only)
+            uint32_t iters = 1;
+            if (VEC && g->geom.cols_log2 >= 0) {
+                static const int forced = [] { const char *e = getenv("ISINGMC_SWEEP_ITERS"); return e ? atoi(e) : 0; }();
+                const uint32_t want = forced ? uint32_t(forced) : (PMJ ? 1u : 2u);
+                if (want > 1 && g->geom.nquads % (256 * want) == 0 &&
+                    (forced || size_t(g->geom.nquads / (256 * want)) * n >= size_t(16) * 256))
+                    iters = want;
+            }
+            if (iters > 1)
+                hipLaunchKernelGGL(lat_sweep_loop_kernel<PMJ>, dim3(g->geom.nquads / (256 * iters), unsigned(n), 1), dim3(256), dbg_lds, stream,
+                                   s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
+                                   s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform, iters);
+            else if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_kernel<VEC, PMJ, VEC>); // division-free mapping
             else launch(lat_sweep_kernel<VEC, PMJ, false>);
         }
     }

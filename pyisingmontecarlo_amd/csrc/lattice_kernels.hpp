@@ -463,6 +463,34 @@ __global__ __launch_bounds__(256) void lat_sweep_kernel(
                                PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid);
 }
 
+// Looping variant for large launches (VEC + 2^k mapping): a thread decides `iters` quads, `stride` threads
+// apart, one after the other (a rolled loop: same code size, same registers).  A wave of the one-quad kernel
+// lives ~7 us and its slot then stays empty until the dispatcher has launched the next workgroup -- on average
+// 6.8 of the 8 wave slots of a SIMD were occupied (SQ_WAVE_CYCLES), and the kernel loses 9 % going from 8 to 6.
+// Here the slot is refilled by the wave's own next iteration, and the prologue (kernel arguments, key, round
+// keys, threshold bits) is paid once per `iters` quads.  Same quads, same counters: bit-identical.
+template <bool PMJ>
+__global__ __launch_bounds__(256) void lat_sweep_loop_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t,
+    const uint2 *__restrict__ keys, const LatThr thr_uniform, const LatThr *__restrict__ thr_replica,
+    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform, const uint32_t iters)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t stride = gridDim.x * 256; // g.nquads == iters * stride (checked by the host)
+    uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    BufPlanes mem;
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
+    mem.own_off = colour * g.wpp * 4u;
+    mem.oth_off = (1 - colour) * g.wpp * 4u;
+    const uint2 key = keys[r];
+    const PhiloxVKeys vk = philox_vkeys(key);
+    const LatThr thr = thr_replica ? thr_replica[r] : thr_uniform;
+    const uint32_t *jn = PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr;
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; it++, gid += stride)
+        update_quad<true, PMJ, true>(mem, g, colour, t, key, vk, thr, jn, jneg_uniform, gid);
+}
+
 // Random initial configuration: word w of plane c = Philox(key, (0, w>>2, c<<8, "LATI"))[w&3].
 __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
                                                        const uint2 *__restrict__ keys,
