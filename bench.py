@@ -145,7 +145,7 @@ def main():
                        "replicas_per_gpu": R, "lattice": [L, L], "beta": BETA, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(),
-                         "kernel": "lat_sweep_kernel<VEC,uniformJ>",
+                         "kernel": "lat_sweep_loop_kernel<uniformJ> (2 quads per thread)",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": device_ms * 1e3 / launches},
             "device_attempts_per_s": R * nvars * args.steps / (device_ms * 1e-3),
