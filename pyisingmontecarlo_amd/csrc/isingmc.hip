@@ -941,13 +941,13 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
                                    s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
                                    s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform);
             };
-            // large uniform-J launches: every thread loops over two quads (measured: 2 quads +4 %, 4 +2.7 %, 8 +1.3 %;
-            // the +-J kernel needs 66 VGPRs in the loop form -- 7 waves per SIMD -- and loses 2 %).
+            // large launches: every thread loops over two quads (measured: 2 quads +4 %, 4 +2.7 %, 8 +1.3 % on
+            // uniform J; +-J: 2 quads +2.6 %, 4 quads -2 %).  Workgroups of 128 or 64 threads: no gain.
             // ISINGMC_SWEEP_ITERS=1|2|4|8 forces the choice (measurement only)
             uint32_t iters = 1;
             if (VEC && g->geom.cols_log2 >= 0) {
                 static const int forced = [] { const char *e = getenv("ISINGMC_SWEEP_ITERS"); return e ? atoi(e) : 0; }();
-                const uint32_t want = forced ? uint32_t(forced) : (PMJ ? 1u : 2u);
+                const uint32_t want = forced ? uint32_t(forced) : 2u;
                 if (want > 1 && g->geom.nquads % (256 * want) == 0 &&
                     (forced || size_t(g->geom.nquads / (256 * want)) * n >= size_t(16) * 256))
                     iters = want;
