@@ -388,20 +388,24 @@ def test_packed_path_is_selected_for_large_uniform_graphs(capi, oracle, exact):
         np.testing.assert_array_equal(st2.states()[r].astype(np.uint8), s_c)
 
 
-def test_large_launch_takes_the_looping_kernel_bit_exact(capi, oracle, exact):
+@pytest.mark.parametrize("glass", [False, True])
+def test_large_launch_takes_the_looping_kernel_bit_exact(capi, oracle, exact, glass):
     """512 x 512 x 2048 replicas = 2 x 2048 workgroups of quad pairs per launch: the host picks
-    lat_sweep_loop_kernel (two quads per thread).  Replicas are independent, so the first, two middle and
-    the last one against the oracle pin the whole launch."""
+    lat_sweep_loop_kernel (two quads per thread; uniform J and +-J instantiations).  Replicas are independent,
+    so the first, two middle and the last one against the oracle pin the whole launch."""
     W, H, R, T, beta = 512, 512, 2048, 3, 0.4407
-    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0, np.random.default_rng(5) if glass else None)
     g = capi.Graph(ea, eb, ej)
-    assert g.kind == capi.KIND_LATTICE2D
+    assert g.kind == capi.KIND_LATTICE2D and bool(g.info.uniform_sign) != glass
     seeds = capi.make_seeds(99, R)
     st = capi.States(g, seeds)
     st.do_time_steps(T, beta)
     packed = st.packed()
     energies = st.energies()
-    lat = oracle.Lat(W, H, 1.0, 0)
+    if glass:
+        lat = oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8))
+    else:
+        lat = oracle.Lat(W, H, 1.0, 0)
     for r in (0, 777, 1024, R - 1):
         ref = lat.init(seeds[r])
         for t in range(T):
