@@ -101,6 +101,7 @@ struct isingmc_states {
     double *d_beta = nullptr;
     // measurement scratch
     unsigned long long *d_meas = nullptr; // lattice: [R][2]
+    bool meas_zero = false;               // d_meas is known to be all zero (left so by the tempering measurement)
     double *d_pe = nullptr, *d_oe = nullptr;
     long long *d_pm = nullptr, *d_om = nullptr;
     uint32_t n_partials = 0;
@@ -612,6 +613,7 @@ static int reserve(isingmc_states *s, size_t cap)
     TRY(dev_alloc(&s->d_beta, cap));
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
         TRY(dev_alloc(&s->d_meas, 2 * cap));
+        s->meas_zero = false;
     } else {
         s->n_partials = (g->gdev.n_pos + 255) / 256;
         TRY(dev_alloc(&s->d_pe, cap * s->n_partials));
@@ -760,6 +762,7 @@ static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const u
     TRY(dev_alloc(&s->d_state, s->groups * g->pk.n_pos));
     TRY(dev_alloc(&s->d_keys, s->groups));
     TRY(dev_alloc(&s->d_meas, 2 * n));
+    s->meas_zero = false;
     std::vector<uint2> keys(s->groups);
     for (size_t k = 0; k < s->groups; k++) keys[k] = make_uint2(uint32_t(seeds[32 * k]), uint32_t(seeds[32 * k] >> 32));
     HIP_TRY(hipMemcpy(s->d_keys, keys.data(), keys.size() * sizeof(uint2), hipMemcpyHostToDevice));
@@ -830,6 +833,7 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
     HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+    s->meas_zero = false;
     const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(1024, g->pk.n_pos / 2048)));
     for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
         const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
@@ -1059,6 +1063,7 @@ static int measure(isingmc_states *s, double *energies, int64_t *mags)
     if (s->packed) return pk_measure(s, energies, mags);
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
         HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        s->meas_zero = false;
         LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
         HIP_TRY(hipGetLastError());
         std::vector<unsigned long long> h(2 * R);
@@ -1512,15 +1517,17 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
     const size_t R = s->R;
     if (R == 0) return ISINGMC_OK;
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        // three launches per round: the conversion kernel leaves the counters zeroed for the next round and, on
+        // a single rank, writes straight into the gathered array (no memset, no device-to-device copy)
+        if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
         LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
         hipLaunchKernelGGL(lat_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas,
-                           uint32_t(R), g->jabs, 2ll * (long long)g->nvars, s->d_pt_local);
+                           uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
+                           s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
+        s->meas_zero = true;
     } else {
         return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path; use the host swap step");
     }
-    if (s->pt_world == 1)
-        HIP_TRY(hipMemcpyAsync(s->d_pt_all + s->pt.slot_offset, s->d_pt_local, R * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipGetLastError());
     return ISINGMC_OK;
 }

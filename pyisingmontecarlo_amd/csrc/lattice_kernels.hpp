@@ -624,11 +624,15 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
 }
 
 // lattice energies from the satisfied-bond counters: E = |J| (n_bonds - 2 sat)  (exact in f64)
-__global__ void lat_energy_from_counts_kernel(const unsigned long long *__restrict__ meas, const uint32_t n,
+__global__ void lat_energy_from_counts_kernel(unsigned long long *__restrict__ meas, const uint32_t n,
                                               const double jabs, const long long n_bonds, double *__restrict__ out)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) out[r] = jabs * double(n_bonds - 2 * (long long)meas[2 * size_t(r)]);
+    if (r < n) {
+        out[r] = jabs * double(n_bonds - 2 * (long long)meas[2 * size_t(r)]);
+        meas[2 * size_t(r)] = 0; // the counters are left zeroed for the next measurement (no memset per round)
+        meas[2 * size_t(r) + 1] = 0;
+    }
 }
 
 } // namespace isingmc
