@@ -49,7 +49,7 @@ def _lattice_case(capi, oracle, exact, W, H, J, beta, T, rng=None, per_step=Fals
     return st
 
 
-@pytest.mark.parametrize("W,H", [(64, 64), (128, 32), (256, 64), (512, 16), (64, 4)])
+@pytest.mark.parametrize("W,H", [(64, 64), (128, 32), (256, 64), (512, 16), (64, 4), (16384, 16), (8192, 6)])
 @pytest.mark.parametrize("beta", [0.4407, 0.0, 1.5])
 def test_lattice_uniform_ferro_bit_exact(capi, oracle, exact, W, H, beta):
     _lattice_case(capi, oracle, exact, W, H, -1.0, beta, T=6)
