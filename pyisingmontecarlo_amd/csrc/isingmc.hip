@@ -834,7 +834,7 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     const size_t R = s->R;
     HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
     s->meas_zero = false;
-    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(1024, g->pk.n_pos / 2048)));
+    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + PK_MEASURE_CHUNK - 1) / PK_MEASURE_CHUNK)));
     for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
         const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
         hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
@@ -1322,7 +1322,7 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
     const size_t R = s->R;
     if (s->packed) {
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
-        const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(1024, g->pk.n_pos / 2048)));
+        const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + PK_MEASURE_CHUNK - 1) / PK_MEASURE_CHUNK)));
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
             hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
