@@ -851,6 +851,8 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     return ISINGMC_OK;
 }
 
+static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot);
+
 static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
                         double *energies_per_step, float *device_ms, bool sync)
 {
@@ -860,6 +862,14 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     uint32_t *d_step_tabs = nullptr;
     const size_t chunk = std::min<size_t>(timesteps, 2048);
     if (!s->has_betas) TRY(scratch.alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
+    // energies after every timestep: the measurements are enqueued behind their sweeps into one counter slot
+    // per step; the host reads a whole chunk at once
+    unsigned long long *d_step_counts = nullptr;
+    std::vector<unsigned long long> h_step_counts;
+    if (energies_per_step) {
+        TRY(scratch.alloc(&d_step_counts, chunk * R * 2));
+        h_step_counts.resize(chunk * R * 2);
+    }
     std::vector<uint32_t> h_tabs;
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -877,13 +887,16 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
             else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
             s->t++;
-            if (energies_per_step) {
-                std::vector<double> e(R);
-                rc = pk_measure(s, e.data(), nullptr);
-                for (size_t r = 0; r < R && rc == ISINGMC_OK; r++) energies_per_step[r * timesteps + k0 + k] = e[r];
-            }
+            if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * R * 2, nullptr, nullptr);
         }
-        if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
+        if (energies_per_step && rc == ISINGMC_OK) {
+            HIP_TRY(hipMemcpyAsync(h_step_counts.data(), d_step_counts, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            for (size_t k = 0; k < nk; k++)
+                for (size_t r = 0; r < R; r++) // as in pk_measure: directed counts are doubled
+                    energies_per_step[r * timesteps + k0 + k] =
+                        g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_step_counts[(k * R + r) * 2]))) + g->self_energy;
+        } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (device_ms && rc == ISINGMC_OK) {
         hipError_t err = hipEventRecord(s->ev1, s->stream);
@@ -1138,9 +1151,13 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
+    long long *d_gen_mags = nullptr;
     if (gen_resident) {
         if (!s->has_betas) TRY(scratch.alloc(&d_beta_steps, beta_stride ? chunk : 1));
         if (energies_per_step) TRY(scratch.alloc(&d_gen_energies, chunk * R));
+    } else if (!lattice && energies_per_step) { // CSR path: one reduction slot per step, read back per chunk
+        TRY(scratch.alloc(&d_gen_energies, chunk * R));
+        TRY(scratch.alloc(&d_gen_mags, R));
     }
     unsigned long long *d_steps = nullptr;
     LatThr *d_thr_steps = nullptr;
@@ -1221,11 +1238,17 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             }
             s->t++;
             if (energies_per_step && !lattice) {
-                std::vector<double> e(R);
-                rc = measure(s, e.data(), nullptr);
+                rc = measure_enqueue(s, nullptr, d_gen_energies + (k - k0) * R, d_gen_mags);
                 if (rc != ISINGMC_OK) break;
-                for (size_t r = 0; r < R; r++) energies_per_step[r * timesteps + k] = e[r];
             }
+        }
+        if (energies_per_step && !lattice && !gen_resident && rc == ISINGMC_OK) {
+            std::vector<double> he(nk * R);
+            hipError_t err = hipMemcpyAsync(he.data(), d_gen_energies, he.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+            if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+            for (size_t k = 0; k < nk; k++)
+                for (size_t r = 0; r < R; r++) energies_per_step[r * timesteps + k0 + k] = he[k * R + r] + g->self_energy;
         }
         if (d_steps && rc == ISINGMC_OK) {
             hipError_t err = hipMemcpyAsync(h_steps.data(), d_steps, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);

@@ -363,3 +363,29 @@ def test_run_sampling_equals_step_by_step_loop(capi, exact, monkeypatch, kind):
     assert np.array_equal(a.states(), b.states())
     e0, s0 = a.run_sampling(0.45, 2, 3, 0)                        # no samples: thermalisation only
     assert e0.shape == (R, 0) and a.timestep == 15
+
+
+@pytest.mark.parametrize("kind", ["csr_streaming", "packed"])
+def test_per_step_energies_equal_step_by_step_measurements(capi, exact, monkeypatch, kind):
+    """Energies after every timestep (lattice.rs:445-455) on the non-resident CSR path and on the replica-packed
+    path: the measurements are enqueued behind their sweeps and read back per chunk; they must equal one
+    get_energies call after every single step."""
+    if kind == "packed":
+        ea, eb, ej = exact.cubic_lattice_edges(40, -1.0)            # 64 000 sites: too big for the LDS-resident kernel
+        R, beta = 40, 0.25
+    else:
+        monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", "1")
+        monkeypatch.setenv("ISINGMC_DISABLE_PACKED", "1")
+        rng = np.random.default_rng(7)
+        ea = rng.integers(0, 3000, 9000).astype(np.uint64); eb = rng.integers(0, 3000, 9000).astype(np.uint64)
+        ej = rng.normal(size=9000)
+        R, beta = 5, 0.7
+    seeds = capi.make_seeds(11, R)
+    g = capi.Graph(ea, eb, ej)
+    a = capi.States(g, seeds)
+    eps = a.do_time_steps(7, beta, per_step_energies=True)
+    b = capi.States(g, seeds)
+    for k in range(7):
+        b.do_time_steps(1, beta)
+        np.testing.assert_allclose(eps[:, k], b.energies(), rtol=1e-12, atol=1e-9)
+    assert np.array_equal(a.packed(), b.packed())
