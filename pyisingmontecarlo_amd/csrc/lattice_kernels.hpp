@@ -14,6 +14,7 @@
 // Philox word each.  Everything is integer: the CPU oracle reproduces the configurations bit for bit.
 #pragma once
 #include "philox.hpp"
+#include <type_traits>
 
 namespace isingmc {
 
@@ -422,11 +423,81 @@ __device__ __forceinline__ void quad_flips(const uint32_t own[4], const QuadNbr 
 // One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
 // plane `own_plane`, reading its neighbours from `oth_plane`.  The planes may live in HBM (sweep kernel)
 // or in LDS (resident kernel): the function only sees pointers.
+// Streaming kernels under the 2^k mapping: thread -> quad and the five load offsets with as little VECTOR
+// arithmetic as possible (the kernel is bound by vector-ALU cycles; the scalar unit is idle beside it).
+// The wave index, the row parity and the "does this wave touch row 0 or row H-1" test are wave-uniform and
+// live on the scalar unit; the plane offsets ride in the buffer instructions' scalar offset; rows wrap
+// per lane only in the two waves per plane that contain a boundary row; the row length is a power of two, so
+// the side word's wrap is an AND.  Same quads, same words as thread_to_quad<true> + load_quad<true, true>.
+__device__ __forceinline__ void load_quad_uni(const BufPlanes &mem, const LatGeom &g, const uint32_t colour, const uint32_t gid,
+                                              uint32_t &Q, uint32_t &vQ, uint32_t own[4], QuadNbr &n)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t cl = uint32_t(g.cols_log2), rb = 16u << cl; // row bytes of a plane
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(gid >> 6), lane = gid & 63u;
+    uint32_t y, col;
+    bool lo_row, hi_row; // wave-uniform: the wave contains row 0 / row H-1
+    uint32_t ypar;       // wave-uniform: y & 1
+    if (cl >= 6) {       // a wave never leaves its row: y itself is wave-uniform
+        const uint32_t ys = wave >> (cl - 6);
+        y = ys;
+        col = gid & ((1u << cl) - 1);
+        lo_row = ys == 0;
+        hi_row = ys + 1 == g.H;
+        ypar = ys & 1u;
+    } else {
+        const uint32_t rpw = 64u >> cl, ybase = ((wave >> 1) << (7 - cl)) + (wave & 1u);
+        y = ybase + 2 * (lane >> cl);
+        col = lane & ((1u << cl) - 1);
+        lo_row = ybase == 0;
+        hi_row = ybase + 2 * (rpw - 1) + 1 >= g.H;
+        ypar = wave & 1u;
+    }
+    Q = (y << cl) + col;
+    vQ = Q << 4;
+    uint32_t vU, vD;
+    if (lo_row | hi_row) { // two waves per plane: per-lane wrap
+        const uint32_t yu = (y == 0 ? g.H : y) - 1, yd = (y + 1 == g.H) ? 0 : y + 1;
+        vU = ((yu << cl) + col) << 4;
+        vD = ((yd << cl) + col) << 4;
+    } else {
+        vU = vQ - rb;
+        vD = vQ + rb;
+    }
+    const bool odd = ((ypar + colour) & 1u) != 0;
+    const uint32_t t16 = vQ & (rb - 1), rowb = vQ - t16;
+    const uint32_t vS = rowb + (odd ? ((t16 + 16) & (rb - 1)) : ((t16 - 4) & (rb - 1)));
+    const u32x4 o4 = __builtin_amdgcn_raw_buffer_load_b128(mem.rsrc, vQ, mem.own_off, 0);
+    const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(mem.rsrc, vQ, mem.oth_off, 0);
+    const u32x4 u4 = __builtin_amdgcn_raw_buffer_load_b128(mem.rsrc, vU, mem.oth_off, 0);
+    const u32x4 d4 = __builtin_amdgcn_raw_buffer_load_b128(mem.rsrc, vD, mem.oth_off, 0);
+    const uint32_t sw = __builtin_amdgcn_raw_buffer_load_b32(mem.rsrc, vS, mem.oth_off, 0);
+    own[0] = o4.x; own[1] = o4.y; own[2] = o4.z; own[3] = o4.w;
+    n.ce[0] = c4.x; n.ce[1] = c4.y; n.ce[2] = c4.z; n.ce[3] = c4.w;
+    n.up[0] = u4.x; n.up[1] = u4.y; n.up[2] = u4.z; n.up[3] = u4.w;
+    n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
+    n.si[0] = sw;
+    side_words(n, odd);
+}
+
 template <bool VEC, bool PMJ, bool UNI, typename Mem>
 __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
                                             const PhiloxVKeys &vk, const LatThr thr, const uint32_t *__restrict__ jn,
                                             const uint32_t jneg_uniform, const uint32_t gid)
 {
+    if constexpr (VEC && UNI && std::is_same<Mem, BufPlanes>::value) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint32_t Q, vQ, own[4], acc[4];
+        QuadNbr n;
+        QuadSigns js;
+        load_quad_uni(mem, g, colour, gid, Q, vQ, own, n);
+        load_signs<PMJ>(jn, g, Q, js);
+        const uint32_t widx[4] = {4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3};
+        quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
+                                               vQ, mem.own_off, 0);
+        return;
+    }
     uint32_t Q, qy, qxw;
     thread_to_quad<UNI>(g, gid, Q, qy, qxw);
 
