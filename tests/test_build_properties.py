@@ -1,0 +1,53 @@
+"""Code-generation properties the measured performance depends on (no GPU needed: hipcc cross-compiles).
+
+The sweep kernels are bound by vector-ALU cycles and need all 8 wave slots of a SIMD: 64 VGPRs is the limit.
+A behaviour-neutral source change once compiled the looping kernel to 66 VGPRs and cost 3 % (DESIGN.md
+section 4); this test makes such a drift visible on the CPU box."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "isingmc.s"
+    src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "isingmc.hip")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _kernel_meta(asm, mangled_prefix):
+    metas = []
+    for m in re.finditer(r"\.name:\s+(" + re.escape(mangled_prefix) + r"\w*)", asm):
+        after = asm[m.start():m.start() + 900]
+        before = asm[max(0, m.start() - 700):m.start() + 900]
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", after).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", after).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", before).group(1))
+        metas.append((m.group(1), vgpr, spill, scratch))
+    return metas
+
+
+@pytest.mark.parametrize("prefix", ["_ZN7isingmc21lat_sweep_loop_kernel", "_ZN7isingmc16lat_sweep_kernel"])
+def test_sweep_kernels_keep_eight_waves_per_simd(device_asm, prefix):
+    metas = _kernel_meta(device_asm, prefix)
+    assert metas, "kernel not found in the device assembly"
+    for name, vgpr, spill, scratch in metas:
+        if prefix.endswith("loop_kernel") and "ILb1E" in name:
+            continue  # the +-J looping instantiation needs 66-68 registers (7 waves); measured faster than the alternatives
+        assert vgpr <= 64, f"{name}: {vgpr} VGPRs (> 64: fewer than 8 waves per SIMD)"
+        assert spill == 0 and scratch == 0, f"{name}: spills to scratch"
+
+
+def test_packed_sweep_kernel_does_not_spill(device_asm):
+    for name, vgpr, spill, scratch in _kernel_meta(device_asm, "_ZN7isingmc15pk_sweep_kernel"):
+        assert vgpr <= 72 and spill == 0 and scratch == 0, f"{name}: {vgpr} VGPRs, {spill} spills"
