@@ -728,13 +728,23 @@ static bool env_flag(const char *name)
 }
 
 // worth it from 16 replicas on and when the graph is too big for the LDS-resident per-replica kernel
+// LDS-resident kernel for small graphs only: one workgroup walks a whole replica, ~13 us + 2.8..5 ns per site
+// and timestep whatever the replica count, against n_colours x (5 + 0.2 R) us of launches for the per-colour
+// kernels -- measured crossover 8 000 sites at 4 replicas, 32 000 at 64 (tools/resident_threshold.py); a
+// 200 000-site graph ran 13x slower resident than streamed.
+static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
+{
+    return g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES &&
+           double(g->nvars) <= 4000.0 * std::sqrt(double(std::min<size_t>(std::max<size_t>(n_replicas, 1), 64)));
+}
+
 static bool choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return false;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return false;
     if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0;
-    return n_replicas >= 16 && g->state_words * sizeof(uint32_t) > GEN_RESIDENT_MAX_BYTES;
+    return n_replicas >= 16 && !gen_resident_fits(g, n_replicas);
 }
 
 // threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)
@@ -1147,7 +1157,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
                           !resident_disabled();
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
-    const bool gen_resident = !lattice && g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && !resident_disabled();
+    const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
     if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
