@@ -729,13 +729,12 @@ static bool env_flag(const char *name)
 
 // worth it from 16 replicas on and when the graph is too big for the LDS-resident per-replica kernel
 // LDS-resident kernel for small graphs only: one workgroup walks a whole replica, ~13 us + 2.8..5 ns per site
-// and timestep whatever the replica count, against n_colours x (5 + 0.2 R) us of launches for the per-colour
-// kernels -- measured crossover 8 000 sites at 4 replicas, 32 000 at 64 (tools/resident_threshold.py); a
+// and timestep whatever the replica count, against ~5 us per colour class for the per-colour launches --
+// measured crossover ~8 000 sites at 4 replicas, ~14 000 at 64 (profiles/r01_resident_threshold.txt); a
 // 200 000-site graph ran 13x slower resident than streamed.
 static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
 {
-    return g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES &&
-           double(g->nvars) <= 4000.0 * std::sqrt(double(std::min<size_t>(std::max<size_t>(n_replicas, 1), 64)));
+    return g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && g->nvars <= (n_replicas < 16 ? 8000u : 12000u);
 }
 
 static bool choose_packed(const isingmc_graph *g, size_t n_replicas)
@@ -1067,13 +1066,20 @@ static void launch_gen_timestep(isingmc_states *s, double beta)
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
         if (e == b) continue;
-        if (s->R >= GEN_RB) {
-            if (g->w_is_float) launch_gen_class<float, GEN_RB>(s, b, e, beta);
-            else launch_gen_class<double, GEN_RB>(s, b, e, beta);
-        } else {
-            if (g->w_is_float) launch_gen_class<float, 1>(s, b, e, beta);
-            else launch_gen_class<double, 1>(s, b, e, beta);
-        }
+        // replicas per thread: GEN_RB amortises the CSR stream of a big class; a class that would leave the chip
+        // short of workgroups (< 8 per CU) halves it until the grid is large enough
+        // (200 000 sites x 64 replicas: 56 us per launch at 8 replicas per thread)
+        size_t rb = GEN_RB;
+        const size_t blocks = (e - b + 255) / 256;
+        while (rb > 1 && (s->R < rb || blocks * ((s->R + rb - 1) / rb) < 2048)) rb /= 2;
+        const auto launch = [&](auto wt) {
+            using WT = decltype(wt);
+            if (rb >= 8) launch_gen_class<WT, 8>(s, b, e, beta);
+            else if (rb == 4) launch_gen_class<WT, 4>(s, b, e, beta);
+            else if (rb == 2) launch_gen_class<WT, 2>(s, b, e, beta);
+            else launch_gen_class<WT, 1>(s, b, e, beta);
+        };
+        if (g->w_is_float) launch(float(0)); else launch(double(0));
     }
 }
 
