@@ -475,7 +475,25 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
             for (uint32_t p = 0; p < n_pos; p++)
                 for (uint32_t e = rowptr[p]; e < rowptr[p + 1]; e++)
                     ell[size_t(e - rowptr[p]) * n_pos + p] = nbr[e] | (w[e] > 0.0 ? 0x80000000u : 0u);
+            // block headers: a slot whose 64 entries of a block are one translation (or all unused) needs no table read
+            const size_t n_blocks = n_pos / 64;
+            std::vector<uint2> hdr(n_blocks * PK_MAX_DEG);
+            parallel_for(n_blocks, [&](size_t B) {
+                for (uint32_t i = 0; i < uint32_t(PK_MAX_DEG); i++) {
+                    const uint32_t *e = ell.data() + size_t(i) * n_pos + 64 * B;
+                    const uint32_t p0 = uint32_t(64 * B);
+                    bool unused = true, uniform = e[0] != PK_NO_NBR;
+                    const uint32_t sign = e[0] & 0x80000000u, delta = (e[0] & 0x7FFFFFFFu) - p0;
+                    for (uint32_t l = 0; l < 64; l++) {
+                        unused &= e[l] == PK_NO_NBR;
+                        uniform &= e[l] != PK_NO_NBR && (e[l] & 0x80000000u) == sign && (e[l] & 0x7FFFFFFFu) - (p0 + l) == delta;
+                    }
+                    hdr[B * PK_MAX_DEG + i] = unused ? make_uint2(PK_HDR_UNUSED, 0) : uniform ? make_uint2(PK_HDR_UNIFORM | sign, delta)
+                                                                                           : make_uint2(PK_HDR_MIXED, 0);
+                }
+            });
             PkGraphDev &P = g->pk;
+            TRY(graph_upload(g, &P.ell_hdr, hdr));
             TRY(graph_upload(g, &P.nbr_ell, ell));
             P.site = D.site;
             P.class_base = D.class_base;

@@ -32,13 +32,31 @@ constexpr uint32_t PK_TAB_WORDS = PK_TAB_LO + PK_MAX_DEG * 32;
 
 constexpr uint32_t PK_NO_NBR = 0xFFFFFFFFu;
 
+// Block headers of the ELL table: block B = positions [64 B, 64 B + 64) -- exactly what the 64 lanes of a wave
+// touch for one word of their quads.  Where a slot's 64 entries are one translation (same offset to the own
+// position, same coupling sign: the interior of any lattice-like graph) or all unused, the header replaces
+// them: the wave reads 8 bytes through the scalar unit instead of 256 from the table.
+constexpr uint32_t PK_HDR_MIXED = 0, PK_HDR_UNIFORM = 1, PK_HDR_UNUSED = 2; // .x bits 0-1; .x bit 31 = J > 0; .y = offset
+
 struct PkGraphDev {
+    const uint2 *ell_hdr;       // [n_pos / 64][PK_MAX_DEG]
     const uint32_t *nbr_ell;    // [PK_MAX_DEG][n_pos]: neighbour position | (J > 0) << 31, or PK_NO_NBR
     const uint32_t *site;       // original site per position, PAD_SITE on padding
     const uint32_t *class_base; // n_colours + 1, multiples of 256
     uint32_t n_colours;
     uint32_t n_pos;             // multiple of 256
 };
+
+// ELL slot of position p: from the (wave-uniform) block header where the block is a translation or unused,
+// else from the table
+__device__ __forceinline__ uint32_t pk_slot(const uint2 h, const __amdgpu_buffer_rsrc_t ell_rsrc, const uint32_t slot_base,
+                                            const uint32_t p)
+{
+    const uint32_t kind = __builtin_amdgcn_readfirstlane(h.x & 3u);
+    if (kind == PK_HDR_MIXED) return __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (slot_base + p), 0, 0);
+    if (kind == PK_HDR_UNUSED) return PK_NO_NBR;
+    return (p + h.y) | (h.x & 0x80000000u);
+}
 
 // satisfied-bond count of the 32 replicas at one position, bit-sliced (c0 = LSB), from its ELL slots x[] and the
 // gathered neighbour words n[].  Fixed trip count with predication.
@@ -91,10 +109,11 @@ __global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ st
 #pragma unroll
     for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
 #pragma unroll
-    for (int i = 0; i < PK_MAX_DEG; i++)
+    for (int q = 0; q < 4; q++) {
+        const uint2 *hdr = G.ell_hdr + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            x[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0);
+        for (int i = 0; i < PK_MAX_DEG; i++) x[q][i] = pk_slot(hdr[i], ell_rsrc, uint32_t(i) * G.n_pos, p0 + 64 * q);
+    }
 #pragma unroll
     for (int i = 0; i < PK_MAX_DEG; i++)
 #pragma unroll
@@ -218,6 +237,8 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
     __shared__ uint32_t red[2][4][32];
     const uint32_t g = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t *st = state + size_t(g) * G.n_pos;
+    const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
     uint32_t tot_sat = 0, tot_up = 0; // lane r < 32: running totals of replica r over this wave's positions
     for (uint32_t base = blockIdx.x * PK_MEASURE_CHUNK; base < G.n_pos; base += gridDim.x * PK_MEASURE_CHUNK) {
         uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, U[6] = {0, 0, 0, 0, 0, 0};
@@ -227,8 +248,10 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
             if (G.site[p] == PAD_SITE) continue;
             const uint32_t s = st[p];
             uint32_t x[PK_MAX_DEG], n[PK_MAX_DEG];
+            // (the lanes that left the loop above hold no header: the block index is the same for all lanes that remain)
+            const uint2 *hdr = G.ell_hdr + size_t(__builtin_amdgcn_readfirstlane(p >> 6)) * PK_MAX_DEG;
 #pragma unroll
-            for (int i = 0; i < PK_MAX_DEG; i++) x[i] = G.nbr_ell[size_t(i) * G.n_pos + p];
+            for (int i = 0; i < PK_MAX_DEG; i++) x[i] = pk_slot(hdr[i], ell_rsrc, uint32_t(i) * G.n_pos, p);
 #pragma unroll
             for (int i = 0; i < PK_MAX_DEG; i++) n[i] = st[x[i] == PK_NO_NBR ? p : (x[i] & 0x7FFFFFFFu)];
             uint32_t deg, c[3];
