@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t pk_match(uint32_t c0, uint32_t c1, uint32_t 
 }
 
 // one colour class of one timestep; blockIdx.y = replica group
-__global__ __launch_bounds__(256) void pk_sweep_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+__global__ __launch_bounds__(256, 8) void pk_sweep_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
                                                        const uint32_t class_begin, const uint32_t class_end,
                                                        const uint64_t t, const uint2 *__restrict__ group_keys,
                                                        const uint32_t *__restrict__ tabs, const uint32_t tab_stride)

@@ -48,6 +48,8 @@ def test_sweep_kernels_keep_eight_waves_per_simd(device_asm, prefix):
         assert spill == 0 and scratch == 0, f"{name}: spills to scratch"
 
 
-def test_packed_sweep_kernel_does_not_spill(device_asm):
+def test_packed_sweep_kernel_keeps_eight_waves(device_asm):
+    """Capped at 64 VGPRs with __launch_bounds__(256, 8): three spilled registers cost less than the eighth wave
+    gains (the kernel is bound by the latency of its dependent memory phases): +2 % on 256^3 x 64."""
     for name, vgpr, spill, scratch in _kernel_meta(device_asm, "_ZN7isingmc15pk_sweep_kernel"):
-        assert vgpr <= 72 and spill == 0 and scratch == 0, f"{name}: {vgpr} VGPRs, {spill} spills"
+        assert vgpr <= 64 and spill <= 4 and scratch <= 32, f"{name}: {vgpr} VGPRs, {spill} spills, {scratch} B scratch"
