@@ -67,6 +67,8 @@ __device__ __forceinline__ double local_field(const GenGraphDev &G, const uint32
     return field;
 }
 
+constexpr int GEN_ROW_BATCH = 8; // directed edges of a CSR row fetched together
+
 // One colour class of one timestep.  A thread owns one site for RB replicas (blockIdx.y = replica
 // group): the CSR row (index + coupling per directed edge, the dominant stream) is read once per RB
 // replicas instead of once per replica; only the bit gathers stay per replica.  The per-site
@@ -86,13 +88,32 @@ __global__ __launch_bounds__(256) void gen_sweep_kernel(
 #pragma unroll
     for (int k = 0; k < RB; k++) field[k] = 0.0;
     if (site != PAD_SITE) {
-        for (uint32_t e = G.rowptr[p], end = G.rowptr[p + 1]; e < end; e++) {
-            const uint32_t q = G.nbr[e];
-            const double j = double(w[e]);
-            const uint32_t *word = state + size_t(r0) * G.n_words + (q >> 5);
+        // The row in batches of GEN_ROW_BATCH directed edges: all indices and couplings of a batch go out
+        // together, then all state words of a replica -- two round trips per batch.  One edge per loop iteration
+        // (index, then word) was two DEPENDENT round trips per edge: a degree-6 site waited twelve times, and
+        // mid-size launches (too few waves to hide it) ran at a fifth of the big-graph rate.  The sum keeps the
+        // adjacency order (f64 addition is not associative; the oracle adds in that order).
+        const uint32_t end = G.rowptr[p + 1];
+        for (uint32_t e0 = G.rowptr[p]; e0 < end; e0 += GEN_ROW_BATCH) {
+            uint32_t q[GEN_ROW_BATCH];
+            double j[GEN_ROW_BATCH];
 #pragma unroll
-            for (int k = 0; k < RB; k++)
-                if (r0 + k < n_replicas) field[k] += ((word[size_t(k) * G.n_words] >> (q & 31)) & 1u) ? j : -j;
+            for (int i = 0; i < GEN_ROW_BATCH; i++) {
+                const uint32_t e = min(e0 + i, end - 1); // clamped: a valid address; the term is skipped below
+                q[i] = G.nbr[e];
+                j[i] = double(w[e]);
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                if (r0 + k >= n_replicas) break; // wave-uniform
+                const uint32_t *st = state + size_t(r0 + k) * G.n_words;
+                uint32_t word[GEN_ROW_BATCH];
+#pragma unroll
+                for (int i = 0; i < GEN_ROW_BATCH; i++) word[i] = st[q[i] >> 5];
+#pragma unroll
+                for (int i = 0; i < GEN_ROW_BATCH; i++)
+                    if (e0 + i < end) field[k] += ((word[i] >> (q[i] & 31)) & 1u) ? j[i] : -j[i];
+            }
         }
     }
     const double bias = (site != PAD_SITE && G.bias) ? G.bias[p] : 0.0;
