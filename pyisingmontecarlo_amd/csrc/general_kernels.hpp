@@ -53,21 +53,33 @@ __device__ __forceinline__ double det_exp(double x)
     return p * __longlong_as_double((1023ll + k) << 52);
 }
 
+constexpr int GEN_ROW_BATCH = 8; // directed edges of a CSR row fetched together
+
+// sum_e J_e s_q in adjacency order; the row is fetched in batches (see gen_sweep_kernel)
 template <typename WT>
 __device__ __forceinline__ double local_field(const GenGraphDev &G, const uint32_t *__restrict__ st,
                                               uint32_t p)
 {
     const WT *w = static_cast<const WT *>(G.w);
     double field = 0.0;
-    for (uint32_t e = G.rowptr[p], end = G.rowptr[p + 1]; e < end; e++) {
-        const uint32_t q = G.nbr[e];
-        const double j = double(w[e]);
-        field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
+    const uint32_t end = G.rowptr[p + 1];
+    for (uint32_t e0 = G.rowptr[p]; e0 < end; e0 += GEN_ROW_BATCH) {
+        uint32_t q[GEN_ROW_BATCH], word[GEN_ROW_BATCH];
+        double j[GEN_ROW_BATCH];
+#pragma unroll
+        for (int i = 0; i < GEN_ROW_BATCH; i++) {
+            const uint32_t e = min(e0 + i, end - 1);
+            q[i] = G.nbr[e];
+            j[i] = double(w[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < GEN_ROW_BATCH; i++) word[i] = st[q[i] >> 5];
+#pragma unroll
+        for (int i = 0; i < GEN_ROW_BATCH; i++)
+            if (e0 + i < end) field += ((word[i] >> (q[i] & 31)) & 1u) ? j[i] : -j[i];
     }
     return field;
 }
-
-constexpr int GEN_ROW_BATCH = 8; // directed edges of a CSR row fetched together
 
 // One colour class of one timestep.  A thread owns one site for RB replicas (blockIdx.y = replica
 // group): the CSR row (index + coupling per directed edge, the dominant stream) is read once per RB
