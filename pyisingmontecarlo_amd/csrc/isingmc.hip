@@ -861,11 +861,14 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     const size_t R = s->R;
     HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
     s->meas_zero = false;
-    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + PK_MEASURE_CHUNK - 1) / PK_MEASURE_CHUNK)));
+    uint32_t ppt = PK_MEASURE_POS_PER_THREAD; // halved until the launch has >= 1024 workgroups (not below 8: the transpose
+                                              // at the end of a chunk costs as much as ~16 positions)
+    while (ppt > 8 && size_t((g->pk.n_pos + 256 * ppt - 1) / (256 * ppt)) * s->groups < 1024) ppt /= 2;
+    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + 256 * ppt - 1) / (256 * ppt))));
     for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
         const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
         hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
-                           s->d_state + g0 * g->pk.n_pos, g->pk, s->d_meas + 2 * 32 * g0, uint32_t(R - 32 * g0));
+                           s->d_state + g0 * g->pk.n_pos, g->pk, s->d_meas + 2 * 32 * g0, uint32_t(R - 32 * g0), ppt);
     }
     HIP_TRY(hipGetLastError());
     std::vector<unsigned long long> h(2 * R);
@@ -1379,11 +1382,14 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
     const size_t R = s->R;
     if (s->packed) {
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
-        const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + PK_MEASURE_CHUNK - 1) / PK_MEASURE_CHUNK)));
+        uint32_t ppt = PK_MEASURE_POS_PER_THREAD; // halved until the launch has >= 1024 workgroups (not below 8: the transpose
+                                                  // at the end of a chunk costs as much as ~16 positions)
+        while (ppt > 8 && size_t((g->pk.n_pos + 256 * ppt - 1) / (256 * ppt)) * s->groups < 1024) ppt /= 2;
+        const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + 256 * ppt - 1) / (256 * ppt))));
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
             hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
-                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(R - 32 * g0));
+                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(R - 32 * g0), ppt);
         }
     } else if (g->kind == ISINGMC_KIND_LATTICE2D) {
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));

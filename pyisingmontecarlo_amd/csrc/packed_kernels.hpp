@@ -231,8 +231,11 @@ __device__ __forceinline__ void bs_add(uint32_t (&S)[K], const uint32_t (&x)[K2]
     }
 }
 
+// pos_per_thread <= PK_MEASURE_POS_PER_THREAD: fewer positions per thread give a mid-size graph enough workgroups
+// (a thread walks its positions one after the other, each a chain of dependent loads)
 __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restrict__ state, const PkGraphDev G,
-                                                         unsigned long long *__restrict__ out, const uint32_t n_replicas)
+                                                         unsigned long long *__restrict__ out, const uint32_t n_replicas,
+                                                         const uint32_t pos_per_thread)
 {
     __shared__ uint32_t red[2][4][32];
     const uint32_t g = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -240,9 +243,10 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
     uint32_t tot_sat = 0, tot_up = 0; // lane r < 32: running totals of replica r over this wave's positions
-    for (uint32_t base = blockIdx.x * PK_MEASURE_CHUNK; base < G.n_pos; base += gridDim.x * PK_MEASURE_CHUNK) {
+    const uint32_t chunk = 256 * pos_per_thread;
+    for (uint32_t base = blockIdx.x * chunk; base < G.n_pos; base += gridDim.x * chunk) {
         uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, U[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t j = 0; j < PK_MEASURE_POS_PER_THREAD; j++) {
+        for (uint32_t j = 0; j < pos_per_thread; j++) {
             const uint32_t p = base + 256 * j + threadIdx.x;
             if (p >= G.n_pos) break;
             if (G.site[p] == PAD_SITE) continue;
