@@ -1056,6 +1056,24 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
     }
 }
 
+// colour-1 half-sweep fused with the measurement of the finished timestep (single stream: the per-step energy
+// mode does not use replica lanes)
+template <bool VEC, bool PMJ>
+static void launch_lat_sweep_measure(isingmc_states *s, const LatThr &thr, uint64_t t_arg, unsigned long long *out, size_t out_stride)
+{
+    const isingmc_graph *g = s->g;
+    for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
+        const size_t n = std::min(MAX_GRID_Y, s->R - r0);
+        const auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), 0, s->stream, s->d_state + r0 * g->state_words,
+                               g->geom, t_arg, s->d_keys + r0, thr, s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg,
+                               g->jneg_uniform, out + r0 * out_stride, out_stride);
+        };
+        if (VEC && g->geom.cols_log2 >= 0) launch(lat_sweep_measure_kernel<VEC, PMJ, VEC>);
+        else launch(lat_sweep_measure_kernel<VEC, PMJ, false>);
+    }
+}
+
 #define LAT_DISPATCH(fn, ...)                                                                       \
     do {                                                                                            \
         const bool pmj__ = !s->g->uniform_sign;                                                     \
@@ -1197,12 +1215,15 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         TRY(scratch.alloc(&d_gen_mags, R));
     }
     unsigned long long *d_steps = nullptr;
+    size_t step_slots = 1;
     LatThr *d_thr_steps = nullptr;
     std::vector<unsigned long long> h_steps;
     std::vector<LatThr> h_thr;
     if (energies_per_step && lattice) {
-        TRY(scratch.alloc(&d_steps, chunk * R * 2));
-        h_steps.resize(chunk * R * 2);
+        // streaming kernels measure inside the colour-1 half-sweep, into MEASURE_SLOTS partial counters per replica
+        step_slots = resident ? 1 : MEASURE_SLOTS;
+        TRY(scratch.alloc(&d_steps, chunk * R * 2 * step_slots));
+        h_steps.resize(chunk * R * 2 * step_slots);
     }
     if (resident && !s->has_betas) TRY(scratch.alloc(&d_thr_steps, beta_stride ? chunk : 1));
     int rc = ISINGMC_OK;
@@ -1221,7 +1242,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
-        if (d_steps) HIP_TRY(hipMemsetAsync(d_steps, 0, nk * R * 2 * sizeof(unsigned long long), s->stream));
+        if (d_steps) HIP_TRY(hipMemsetAsync(d_steps, 0, nk * R * 2 * step_slots * sizeof(unsigned long long), s->stream));
         if (resident) {
             if (!s->has_betas) {
                 h_thr.resize(beta_stride ? nk : 1);
@@ -1268,8 +1289,8 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             if (lattice) {
                 const LatThr thr = lattice_thresholds(beta, g->jabs);
                 LAT_DISPATCH(launch_lat_sweep, s, 0u, thr, s->t);
-                LAT_DISPATCH(launch_lat_sweep, s, 1u, thr, s->t);
-                if (d_steps) LAT_DISPATCH(launch_lat_measure, s, d_steps + (k - k0) * R * 2, size_t(2));
+                if (d_steps) LAT_DISPATCH(launch_lat_sweep_measure, s, thr, s->t, d_steps + (k - k0) * R * 2 * step_slots, 2 * step_slots);
+                else LAT_DISPATCH(launch_lat_sweep, s, 1u, thr, s->t);
             } else {
                 launch_gen_timestep(s, beta);
             }
@@ -1288,13 +1309,16 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                 for (size_t r = 0; r < R; r++) energies_per_step[r * timesteps + k0 + k] = he[k * R + r] + g->self_energy;
         }
         if (d_steps && rc == ISINGMC_OK) {
-            hipError_t err = hipMemcpyAsync(h_steps.data(), d_steps, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
+            hipError_t err = hipMemcpyAsync(h_steps.data(), d_steps, nk * R * 2 * step_slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
             if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
             if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
             const int64_t nbonds = 2 * int64_t(g->nvars);
             for (size_t k = 0; k < nk; k++)
-                for (size_t r = 0; r < R; r++)
-                    energies_per_step[r * timesteps + k0 + k] = g->jabs * double(nbonds - 2 * int64_t(h_steps[(k * R + r) * 2]));
+                for (size_t r = 0; r < R; r++) {
+                    int64_t sat = 0;
+                    for (size_t sl = 0; sl < step_slots; sl++) sat += int64_t(h_steps[((k * R + r) * step_slots + sl) * 2]);
+                    energies_per_step[r * timesteps + k0 + k] = g->jabs * double(nbonds - 2 * sat);
+                }
         }
     }
     if (s->n_lanes > 1) { const int jrc = lanes_join(s); if (rc == ISINGMC_OK) rc = jrc; }

@@ -480,10 +480,35 @@ __device__ __forceinline__ void load_quad_uni(const BufPlanes &mem, const LatGeo
     side_words(n, odd);
 }
 
-template <bool VEC, bool PMJ, bool UNI, typename Mem>
+// Satisfied bonds and up spins of a colour-1 quad AFTER its update (fused energy measurement): every bond joins
+// a colour-0 and a colour-1 site, so the four bonds of the colour-1 sites cover each bond once, and every
+// colour-0 word is the centre word of exactly one colour-1 quad.  Same totals as lat_measure_kernel.
+template <bool PMJ>
+__device__ __forceinline__ void quad_measure(const uint32_t own_new[4], const QuadNbr &n, const QuadSigns &js,
+                                             const uint32_t jneg_uniform, uint32_t &sat, uint32_t &up)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t a0, a1, a2, a3;
+        if constexpr (PMJ) {
+            a0 = own_new[q] ^ n.up[q] ^ js.w[q][0];
+            a1 = own_new[q] ^ n.dn[q] ^ js.w[q][1];
+            a2 = own_new[q] ^ n.ce[q] ^ js.w[q][2];
+            a3 = own_new[q] ^ n.si[q] ^ js.w[q][3];
+        } else {
+            const uint32_t o = own_new[q] ^ jneg_uniform;
+            a0 = o ^ n.up[q]; a1 = o ^ n.dn[q]; a2 = o ^ n.ce[q]; a3 = o ^ n.si[q];
+        }
+        sat += __popc(a0) + __popc(a1) + __popc(a2) + __popc(a3);
+        up += __popc(own_new[q]) + __popc(n.ce[q]);
+    }
+}
+
+template <bool VEC, bool PMJ, bool UNI, typename Mem, bool MEASURE = false>
 __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
                                             const PhiloxVKeys &vk, const LatThr thr, const uint32_t *__restrict__ jn,
-                                            const uint32_t jneg_uniform, const uint32_t gid)
+                                            const uint32_t jneg_uniform, const uint32_t gid, uint32_t *sat = nullptr,
+                                            uint32_t *up = nullptr)
 {
     if constexpr (VEC && UNI && std::is_same<Mem, BufPlanes>::value) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -496,6 +521,10 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
         quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
                                                vQ, mem.own_off, 0);
+        if constexpr (MEASURE) {
+            const uint32_t own_new[4] = {own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]};
+            quad_measure<PMJ>(own_new, n, js, jneg_uniform, *sat, *up);
+        }
         return;
     }
     uint32_t Q, qy, qxw;
@@ -513,6 +542,54 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
     } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) mem.store1(widx[q], own[q] ^ acc[q]);
+    }
+    if constexpr (MEASURE) {
+        const uint32_t own_new[4] = {own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]};
+        quad_measure<PMJ>(own_new, n, js, jneg_uniform, *sat, *up);
+    }
+}
+
+constexpr uint32_t MEASURE_SLOTS = 16;
+
+// Colour-1 half-sweep that also measures (energies after every timestep, lattice.rs:445-455): out[r * stride] +=
+// satisfied bonds, out[r * stride + 1] += up spins of replica r after this timestep -- what lat_measure_kernel
+// would count in a second pass over the planes.
+template <bool VEC, bool PMJ, bool UNI>
+__global__ __launch_bounds__(256) void lat_sweep_measure_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint64_t t, const uint2 *__restrict__ keys, const LatThr thr_uniform,
+    const LatThr *__restrict__ thr_replica, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
+    unsigned long long *__restrict__ out, const size_t out_stride)
+{
+    // out: [replica][MEASURE_SLOTS][2] -- a workgroup adds into slot blockIdx.x % MEASURE_SLOTS, so that the
+    // workgroups of a replica do not all serialise on one pair of addresses (256 per replica at 4096^2); the host sums
+    __shared__ uint32_t red[2][4];
+    const uint32_t colour = 1;
+    const uint32_t r = blockIdx.y;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    uint32_t sat = 0, up = 0;
+    if (gid < g.nquads) {
+        BufPlanes mem;
+        mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
+        mem.own_off = colour * g.wpp * 4u;
+        mem.oth_off = 0;
+        const uint2 key = keys[r];
+        update_quad<VEC, PMJ, UNI, BufPlanes, true>(mem, g, colour, t, key, philox_vkeys(key), thr_replica ? thr_replica[r] : thr_uniform,
+                                                    PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid, &sat, &up);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sat += __shfl_xor(sat, off);
+        up += __shfl_xor(up, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sat;
+        red[1][threadIdx.x >> 6] = up;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *slot = out + size_t(r) * out_stride + 2 * (blockIdx.x % MEASURE_SLOTS);
+        atomicAdd(slot, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(slot + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
 }
 
