@@ -8,18 +8,24 @@ already in HBM when the timed region starts; edge-list ingest, lattice recogniti
 and the final energy/state read-back are outside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-Replicas are the shard: every rank runs its own 256 replicas (weak scaling), no data-path collective.
-Rank 0 prints ONE JSON line.
+--gpus N > 1 without WORLD_SIZE in the environment: this process starts N rank processes itself
+(torch.distributed.run, rendezvous on 127.0.0.1) BEFORE anything touches a GPU, relays their output and
+exits with their code; launched under torchrun (WORLD_SIZE set) it is one of the ranks.  Replicas are the
+shard: every rank runs its own 256 replicas (weak scaling), no data-path collective.  Rank 0 prints ONE
+JSON line.
+
+Timed region: after `--precondition-s` seconds of the same sweeps (reported as "precondition_s": the chip
+settles its clock a few tens of ms after the load step -- a cold 20-step run reads 20-25 % slow, see
+"cold_ms_per_step") and W warm-up steps, exactly K steps between barrier + synchronize pairs.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,9 +36,38 @@ REPLICAS_PER_GPU = 256
 SEED_GEN = 1
 BYTES_PER_ATTEMPT = 0.375  # read own + other colour plane, write own plane, bit-packed
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_CU, SIMD_PER_CU = 256, 4
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
+    ap.add_argument("--precondition-s", type=float, default=0.5,
+                    help="seconds of untimed sweeps before the counted warm-up (device clock/power settle)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one "
+                         "GPU to rehearse the multi-rank path on a one-GPU box)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """Parent of a bare `python bench.py --gpus N`: start the N ranks, touch no GPU (no torch import here)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def lattice_edges(W, H, J=-1.0):
+    import numpy as np
     ids = np.arange(W * H, dtype=np.uint64).reshape(H, W)
     ea = np.stack([ids, ids], axis=-1).reshape(-1)
     eb = np.stack([np.roll(ids, -1, axis=1), np.roll(ids, -1, axis=0)], axis=-1).reshape(-1)
@@ -52,33 +87,45 @@ def cpu_baseline(ea, eb, ej, nvars):
                       f"{sec:.1f} s; C restatement of the reference algorithm, not the Rust crate"}
 
 
-def traffic_from_profile():
-    """HBM bytes per sweep-kernel launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def _profile_json(name):
     try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except (OSError, ValueError):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one "
-                         "GPU to rehearse the multi-rank path on a one-GPU box)")
-    args = ap.parse_args()
+def traffic_from_profile():
+    """HBM bytes per colour half-sweep (all replicas) from the committed rocprofv3 --pmc passes, or None."""
+    d = _profile_json("traffic_latest.json")
+    return d.get("hbm_bytes_per_launch") if d else None
 
+
+def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
+    """Secondary roofline: the sweep kernel is bound by vector-ALU issue cycles, not by HBM.
+    achieved = VALU-busy SIMD cycles per quad (SQ counters of the same kernel, committed under profiles/);
+    peak = SIMD cycles a quad owns = launch time x live shader clock x SIMDs / quads per launch."""
+    d = _profile_json("sq_latest.json")
+    if not d or not clock_ghz:
+        return None
+    owned = avg_launch_us * 1e-6 * clock_ghz * 1e9 * N_CU * SIMD_PER_CU / quads_per_launch
+    busy = d["valu_busy_cycles_per_quad"]
+    return {"bound": "valu", "achieved": busy, "peak": owned, "unit": "SIMD cycles per quad (128 spins)",
+            "frac": busy / owned, "clock_ghz": clock_ghz, "valu_insts_per_quad": d.get("valu_insts_per_quad"),
+            "source": d.get("source")}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+
+    import numpy as np  # noqa: F401
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist
@@ -112,6 +159,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # cold: the same K steps straight after the random start (reported, never `value`)
+    barrier()
+    cold_ms = states.do_time_steps_timed(args.steps, BETA)
+    # pre-conditioning: >= precondition_s seconds of the same sweeps on the same state
+    t0 = time.perf_counter()
+    pre_steps = 0
+    while time.perf_counter() - t0 < args.precondition_s:
+        states.do_time_steps(50, BETA)
+        pre_steps += 50
+    precondition_s = time.perf_counter() - t0
     states.do_time_steps(args.warmup, BETA)
     barrier()
     t0 = time.perf_counter()
@@ -119,19 +176,30 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
 
-    stats = torch.tensor([wall, device_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    stats = torch.tensor([wall, device_ms, cold_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    wall, device_ms = float(stats[0]), float(stats[1])
+    wall, device_ms, cold_ms = float(stats[0]), float(stats[1]), float(stats[2])
 
-    # sanity outside the timed region: energy per site at beta_c must be near -sqrt(2)
+    # outside the timed region: energy per site at beta_c must be near -sqrt(2); live shader clock under the kernel
     e_site = float(states.energies().mean()) / nvars
+    clock_ghz = states.shader_clock_ghz(60, BETA, probe_ms=10.0) if rank == 0 else None
 
     if rank == 0:
         attempts = world * R * nvars * args.steps
-        launches = 2 * args.steps                       # one kernel launch per colour per step
+        launches = 2 * args.steps                       # one colour half-sweep of all replicas = one "launch"
         bytes_per_launch = BYTES_PER_ATTEMPT * R * nvars / 2
-        achieved = bytes_per_launch / (device_ms * 1e-3 / launches) / 1e9
+        avg_launch_us = device_ms * 1e3 / launches
+        achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(),
+                    "kernel": "lat_sweep_loop_kernel<uniformJ> (2 quads per thread; replicas in 2 stream lanes)",
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": avg_launch_us,
+                    "launch": "one colour half-sweep of all replicas (2 kernel dispatches, one per lane)"}
+        sec = valu_bound(avg_launch_us, clock_ghz, R * nvars / 2 / 128)
+        if sec:
+            roofline["secondary"] = sec
         out = {
             "metric": "spin-flip attempts/s (whole node), 4096^2 2D Ising",
             "value": attempts / wall,
@@ -143,12 +211,11 @@ def main():
             "config": {"workload": f"c2: {L}x{L} periodic Ising J=-1 beta={BETA}, {R} replicas/GPU, "
                                    "checkerboard Metropolis, bit-packed spins, Philox4x32-10",
                        "replicas_per_gpu": R, "lattice": [L, L], "beta": BETA, "parallelism": f"replicas x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(),
-                         "kernel": "lat_sweep_loop_kernel<uniformJ> (2 quads per thread)",
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": device_ms * 1e3 / launches},
+            "precondition_s": precondition_s, "precondition_steps": pre_steps,
+            "cold_ms_per_step": cold_ms / args.steps,
+            "roofline": roofline,
             "device_attempts_per_s": R * nvars * args.steps / (device_ms * 1e-3),
+            "shader_clock_ghz": clock_ghz,
             "energy_per_site": e_site,
             "ingest_s": t_ingest,
         }
@@ -156,6 +223,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ea, eb, ej, nvars)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -116,6 +116,14 @@ void isingmc_graph_destroy(isingmc_graph *graph);
  * (nonzero = True) copied into every replica.  The graph must outlive the states. */
 int isingmc_states_create(isingmc_graph *graph, size_t n_replicas, const uint64_t *seeds,
                           const uint8_t *initial_state, isingmc_states **states_out);
+/* One shard of the same fan-out: experiments [first, first + count) of the n_total whose seeds are
+ * all_seeds[n_total] (the zip of lattice.rs:192-197 cut into contiguous blocks, one per GPU).  Every
+ * choice that shapes a trajectory is made from the GLOBAL experiment index and count, so the union of
+ * the shards' results equals one unsharded call whatever the cut.  isingmc_states_create(g, n, seeds)
+ * is the shard [0, n) of n. */
+int isingmc_states_create_range(isingmc_graph *graph, size_t n_total, const uint64_t *all_seeds,
+                                size_t first, size_t count, const uint8_t *initial_state,
+                                isingmc_states **states_out);
 /* ClassicIsing.add_graph (classicising.rs:62-79): append one replica. */
 int isingmc_states_append(isingmc_states *states, uint64_t seed, const uint8_t *initial_state);
 /* GraphState::set_state (lattice.rs:202) on one replica. */
@@ -187,6 +195,13 @@ int isingmc_pt_state(isingmc_states *states, uint32_t *perm_out, uint64_t *round
 /* the engine's hipStream_t (for enqueuing the collective) and a host-side wait for it */
 int isingmc_states_stream(isingmc_states *states, void **stream_out);
 int isingmc_synchronize(isingmc_states *states);
+
+/* ---- measurement hook (bench.py; no reference counterpart) ------------------------------------------
+ * Runs `timesteps` sweeps at `beta` like isingmc_do_time_steps and, beside them on a side stream, one
+ * wave that stamps the shader-cycle counter against the 100 MHz constant counter for `probe_ms`
+ * milliseconds: *ghz_out = the shader clock the chip holds under this kernel. */
+int isingmc_debug_shader_clock(isingmc_states *states, size_t timesteps, double beta, double probe_ms,
+                               double *ghz_out);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,7 @@ _PROTOTYPES = {
     "isingmc_graph_info": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
     "isingmc_graph_destroy": (None, [_vp]),
     "isingmc_states_create": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.POINTER(_vp)]),
+    "isingmc_states_create_range": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(_vp)]),
     "isingmc_states_append": (C.c_int, [_vp, C.c_uint64, _vp]),
     "isingmc_states_set_state": (C.c_int, [_vp, C.c_size_t, _vp]),
     "isingmc_states_count": (C.c_size_t, [_vp]),
@@ -57,6 +58,7 @@ _PROTOTYPES = {
     "isingmc_pt_state": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "isingmc_states_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "isingmc_synchronize": (C.c_int, [_vp]),
+    "isingmc_debug_shader_clock": (C.c_int, [_vp, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 
@@ -205,14 +207,23 @@ class Graph:
 class States:
     """isingmc_states: R replicas of the graph's spins on the device."""
 
-    def __init__(self, graph, seeds, initial_state=None):
+    def __init__(self, graph, seeds, initial_state=None, replica_range=None):
+        """seeds: one u64 per experiment.  replica_range=(lo, hi): this object is the shard [lo, hi) of the
+        len(seeds) experiments (isingmc_states_create_range: results do not depend on the cut)."""
         self.graph = graph  # keeps the graph alive
         self._h = _vp()
         seeds = _arr(seeds, np.uint64)
         ini = _arr(initial_state, np.uint8)
         if ini is not None and ini.size != graph.nvars:
             raise ValueError("Initial state must be of the same size as biases, or 0.")
-        _check(lib().isingmc_states_create(graph._h, len(seeds), _p(seeds), _p(ini), C.byref(self._h)))
+        if replica_range is None:
+            _check(lib().isingmc_states_create(graph._h, len(seeds), _p(seeds), _p(ini), C.byref(self._h)))
+        else:
+            lo, hi = int(replica_range[0]), int(replica_range[1])
+            if not 0 <= lo <= hi <= len(seeds):
+                raise ValueError("replica_range out of bounds")
+            _check(lib().isingmc_states_create_range(graph._h, len(seeds), _p(seeds), lo, hi - lo, _p(ini),
+                                                     C.byref(self._h)))
 
     @property
     def count(self):
@@ -340,6 +351,12 @@ class States:
 
     def synchronize(self):
         _check(lib().isingmc_synchronize(self._h))
+
+    def shader_clock_ghz(self, timesteps, beta, probe_ms=10.0):
+        """Shader clock held while `timesteps` sweeps run (measurement hook of bench.py)."""
+        ghz = C.c_double()
+        _check(lib().isingmc_debug_shader_clock(self._h, timesteps, float(beta), float(probe_ms), C.byref(ghz)))
+        return ghz.value
 
     def close(self):
         if self._h:

@@ -108,6 +108,8 @@ struct isingmc_states {
     // replica-packed general path: one word per position = 32 replicas of a group
     bool packed = false;
     size_t groups = 0;
+    size_t pk_bit0 = 0; // replica r of this shard is bit (r + pk_bit0) % 32 of group (r + pk_bit0) / 32 (shards cut GLOBAL groups)
+    size_t pk_slots() const { return 32 * groups; } // counter slots: one per (group, bit), owned or not
     uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
     // on-stream parallel tempering (isingmc_pt_*)
     bool pt_attached = false;
@@ -354,7 +356,9 @@ static bool lattice_fast_path_ok(const Lattice2D &L)
 {
     if (!L.ok || L.W % 64 != 0) return false;
     const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
-    return wpp % 4 == 0 && wpp < (uint64_t(1) << 31);
+    // the kernels address a replica through ONE buffer descriptor (int num_records) and 32-bit byte offsets:
+    // both planes must fit below 2^31 bytes; larger lattices take the general path
+    return wpp % 4 == 0 && 2 * wpp * sizeof(uint32_t) < (uint64_t(1) << 31);
 }
 
 static int build_lattice(isingmc_graph *g, const Lattice2D &L)
@@ -576,7 +580,7 @@ static int lanes_reserve(isingmc_states *s, size_t n);
 
 // replica-packed general path (defined further down)
 static bool choose_packed(const isingmc_graph *g, size_t n_replicas);
-static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const uint8_t *initial_state);
+static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state);
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
 static int pk_set_betas(isingmc_states *s);
 
@@ -614,15 +618,22 @@ static int reserve(isingmc_states *s, size_t cap)
     const isingmc_graph *g = s->g;
     uint32_t *d_state = nullptr;
     uint2 *d_keys = nullptr;
+    struct Undo { // a failure below must not leak the new buffers
+        uint32_t **a;
+        uint2 **b;
+        bool armed = true;
+        ~Undo() { if (armed) { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); } }
+    } undo{&d_state, &d_keys};
     TRY(dev_alloc(&d_state, cap * g->state_words));
     TRY(dev_alloc(&d_keys, cap));
     if (s->R) {
         HIP_TRY(hipMemcpy(d_state, s->d_state, s->R * g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->R * sizeof(uint2), hipMemcpyDeviceToDevice));
     }
+    undo.armed = false;
     for (void *p : {(void *)s->d_state, (void *)s->d_keys, (void *)s->d_thr, (void *)s->d_beta, (void *)s->d_meas,
                     (void *)s->d_pe, (void *)s->d_oe, (void *)s->d_pm, (void *)s->d_om})
-        if (p) HIP_TRY(hipFree(p));
+        if (p) (void)hipFree(p);
     s->d_state = d_state;
     s->d_keys = d_keys;
     s->d_thr = nullptr; s->d_beta = nullptr; s->d_meas = nullptr;
@@ -659,12 +670,18 @@ static int add_replicas(isingmc_states *s, size_t count, const uint64_t *seeds, 
     return ISINGMC_OK;
 }
 
-extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const uint64_t *seeds,
-                                     const uint8_t *initial_state, isingmc_states **states_out)
+// Experiments [first, first + count) of n_total (one shard of the rayon fan-out of lattice.rs:192-197).  Everything that
+// shapes a trajectory is decided from the GLOBAL experiment index and count -- the packed / per-replica choice, the
+// 32-replica group a replica belongs to, the group's key and the replica's bit -- so that the results do not depend on
+// how the experiments are cut into shards.  A shard that starts or ends inside a group simulates the whole group
+// (the replicas of a group share Philox words and number their ties together).
+extern "C" int isingmc_states_create_range(isingmc_graph *g, size_t n_total, const uint64_t *all_seeds, size_t first,
+                                           size_t count, const uint8_t *initial_state, isingmc_states **states_out)
 {
     if (!g || !states_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     *states_out = nullptr;
-    if (n_replicas && !seeds) return fail(ISINGMC_ERR_INVALID, "seeds is NULL");
+    if (n_total && !all_seeds) return fail(ISINGMC_ERR_INVALID, "seeds is NULL");
+    if (first > n_total || count > n_total - first) return fail(ISINGMC_ERR_INVALID, "replica range out of bounds");
     TRY(use_device(g->device));
     auto s = std::make_unique<isingmc_states>();
     s->g = g;
@@ -672,14 +689,20 @@ extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const 
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     TRY(lanes_reserve(s.get(), 2)); // created up front: the first multi-lane run must not pay for stream creation
-    if (choose_packed(g, n_replicas)) {
-        TRY(pk_create(s.get(), n_replicas, seeds, initial_state));
+    if (choose_packed(g, n_total) && count) {
+        TRY(pk_create(s.get(), all_seeds, first, count, initial_state));
     } else {
-        TRY(reserve(s.get(), std::max<size_t>(n_replicas, 1)));
-        TRY(add_replicas(s.get(), n_replicas, seeds, initial_state));
+        TRY(reserve(s.get(), std::max<size_t>(count, 1)));
+        TRY(add_replicas(s.get(), count, all_seeds + first, initial_state));
     }
     *states_out = s.release();
     return ISINGMC_OK;
+}
+
+extern "C" int isingmc_states_create(isingmc_graph *g, size_t n_replicas, const uint64_t *seeds,
+                                     const uint8_t *initial_state, isingmc_states **states_out)
+{
+    return isingmc_states_create_range(g, n_replicas, seeds, 0, n_replicas, initial_state, states_out);
 }
 
 extern "C" int isingmc_states_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state)
@@ -717,6 +740,10 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
     for (size_t r = 0; r < s->R; r++)
         if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
+    if (s->packed && s->pk_bit0 != 0)
+        // the replicas of a group number their ties together: a group's trajectory depends on all 32 betas, and this
+        // shard only knows its own
+        return fail(ISINGMC_ERR_INVALID, "per-replica betas on a replica-packed shard: the shard must start on a multiple of 32 experiments");
     s->betas.assign(beta_per_replica, beta_per_replica + s->R);
     if (s->packed) {
         if (s->R) TRY(pk_set_betas(s));
@@ -780,18 +807,23 @@ static void pk_fill_table(uint32_t *tab, double jabs, F &&beta_of)
         }
 }
 
-static int pk_create(isingmc_states *s, size_t n, const uint64_t *seeds, const uint8_t *initial_state)
+static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state)
 {
     const isingmc_graph *g = s->g;
     s->packed = true;
-    s->groups = (n + 31) / 32;
+    const size_t group0 = first / 32; // global groups [group0, group0 + groups) intersect this shard
+    s->pk_bit0 = first % 32;
+    s->groups = (s->pk_bit0 + n + 31) / 32;
     s->R = s->cap = n;
     TRY(dev_alloc(&s->d_state, s->groups * g->pk.n_pos));
     TRY(dev_alloc(&s->d_keys, s->groups));
-    TRY(dev_alloc(&s->d_meas, 2 * n));
+    TRY(dev_alloc(&s->d_meas, 2 * s->pk_slots()));
     s->meas_zero = false;
     std::vector<uint2> keys(s->groups);
-    for (size_t k = 0; k < s->groups; k++) keys[k] = make_uint2(uint32_t(seeds[32 * k]), uint32_t(seeds[32 * k] >> 32));
+    for (size_t k = 0; k < s->groups; k++) { // a group is keyed by the seed of its first GLOBAL replica
+        const uint64_t seed = all_seeds[32 * (group0 + k)];
+        keys[k] = make_uint2(uint32_t(seed), uint32_t(seed >> 32));
+    }
     HIP_TRY(hipMemcpy(s->d_keys, keys.data(), keys.size() * sizeof(uint2), hipMemcpyHostToDevice));
     if (initial_state) { // every replica starts from the same configuration: a word is all ones or all zeros
         std::vector<uint32_t> words(g->pk.n_pos, 0u);
@@ -821,7 +853,7 @@ static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins)
     TRY(scratch.alloc(&d_bits, bits.size()));
     HIP_TRY(hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pk_set_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state,
-                       g->pk.n_pos, d_bits, uint32_t(replica / 32), uint32_t(replica % 32));
+                       g->pk.n_pos, d_bits, uint32_t((replica + s->pk_bit0) / 32), uint32_t((replica + s->pk_bit0) % 32));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
@@ -832,7 +864,7 @@ static int pk_set_betas(isingmc_states *s)
     std::vector<uint32_t> tabs(s->groups * PK_TAB_WORDS);
     for (size_t k = 0; k < s->groups; k++)
         pk_fill_table(tabs.data() + k * PK_TAB_WORDS, s->g->jabs,
-                      [&](uint32_t r) { return s->betas[std::min(s->R - 1, 32 * k + r)]; });
+                      [&](uint32_t r) { return s->betas[std::min(s->R - 1, 32 * k + r)]; }); // pk_bit0 == 0 (checked by the caller)
     if (s->d_tab) HIP_TRY(hipFree(s->d_tab));
     s->d_tab = nullptr;
     TRY(dev_alloc(&s->d_tab, tabs.size()));
@@ -855,39 +887,30 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
     }
 }
 
+static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot);
+
 static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
-    HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+    TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr));
     s->meas_zero = false;
-    uint32_t ppt = PK_MEASURE_POS_PER_THREAD; // halved until the launch has >= 1024 workgroups (not below 8: the transpose
-                                              // at the end of a chunk costs as much as ~16 positions)
-    while (ppt > 8 && size_t((g->pk.n_pos + 256 * ppt - 1) / (256 * ppt)) * s->groups < 1024) ppt /= 2;
-    const unsigned blocks = unsigned(std::max<uint32_t>(1, std::min<uint32_t>(2048, (g->pk.n_pos + 256 * ppt - 1) / (256 * ppt))));
-    for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
-        const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
-        hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
-                           s->d_state + g0 * g->pk.n_pos, g->pk, s->d_meas + 2 * 32 * g0, uint32_t(R - 32 * g0), ppt);
-    }
-    HIP_TRY(hipGetLastError());
-    std::vector<unsigned long long> h(2 * R);
+    std::vector<unsigned long long> h(2 * s->pk_slots());
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (size_t r = 0; r < R; r++) { // E = |J| (undirected bonds - 2 satisfied) + self loops; directed counts are doubled
-        if (energies) energies[r] = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h[2 * r]))) + g->self_energy;
-        if (mags) mags[r] = 2 * int64_t(h[2 * r + 1]) - int64_t(g->nvars);
+        const size_t sl = r + s->pk_bit0;
+        if (energies) energies[r] = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h[2 * sl]))) + g->self_energy;
+        if (mags) mags[r] = 2 * int64_t(h[2 * sl + 1]) - int64_t(g->nvars);
     }
     return ISINGMC_OK;
 }
-
-static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot);
 
 static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
                         double *energies_per_step, float *device_ms, bool sync)
 {
     const isingmc_graph *g = s->g;
-    const size_t R = s->R;
+    const size_t R = s->R, CS = s->pk_slots();
     DeviceScratch scratch(s->stream);
     uint32_t *d_step_tabs = nullptr;
     const size_t chunk = std::min<size_t>(timesteps, 2048);
@@ -897,8 +920,8 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     unsigned long long *d_step_counts = nullptr;
     std::vector<unsigned long long> h_step_counts;
     if (energies_per_step) {
-        TRY(scratch.alloc(&d_step_counts, chunk * R * 2));
-        h_step_counts.resize(chunk * R * 2);
+        TRY(scratch.alloc(&d_step_counts, chunk * CS * 2));
+        h_step_counts.resize(chunk * CS * 2);
     }
     std::vector<uint32_t> h_tabs;
     int rc = ISINGMC_OK;
@@ -917,15 +940,15 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
             else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
             s->t++;
-            if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * R * 2, nullptr, nullptr);
+            if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * CS * 2, nullptr, nullptr);
         }
         if (energies_per_step && rc == ISINGMC_OK) {
-            HIP_TRY(hipMemcpyAsync(h_step_counts.data(), d_step_counts, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(h_step_counts.data(), d_step_counts, nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
             for (size_t k = 0; k < nk; k++)
                 for (size_t r = 0; r < R; r++) // as in pk_measure: directed counts are doubled
                     energies_per_step[r * timesteps + k0 + k] =
-                        g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_step_counts[(k * R + r) * 2]))) + g->self_energy;
+                        g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_step_counts[(k * CS + r + s->pk_bit0) * 2]))) + g->self_energy;
         } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (device_ms && rc == ISINGMC_OK) {
@@ -950,8 +973,8 @@ static int pk_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_
     HIP_TRY(hipMemcpyAsync(words.data(), s->d_state, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     parallel_for(s->R, [&](size_t r) {
-        const uint32_t *w = words.data() + (r / 32) * g->pk.n_pos;
-        const uint32_t bit = uint32_t(r % 32);
+        const uint32_t *w = words.data() + ((r + s->pk_bit0) / 32) * g->pk.n_pos;
+        const uint32_t bit = uint32_t((r + s->pk_bit0) % 32);
         if (states_out) {
             uint8_t *out = states_out + r * replica_stride_bytes;
             for (uint64_t i = 0; i < g->nvars; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
@@ -1201,7 +1224,9 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // (up to 1024 quads per colour: beyond that one workgroup per replica is slower than the launches it saves)
     const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
                           !resident_disabled();
-    size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R))) : timesteps;
+    // per-step counters: 16 B per (step, replica) and counter slot, at most 32 MiB per chunk on each side of the bus
+    const size_t step_slots = (energies_per_step && lattice && !resident) ? MEASURE_SLOTS : 1;
+    size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
     const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
     if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
@@ -1215,13 +1240,11 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         TRY(scratch.alloc(&d_gen_mags, R));
     }
     unsigned long long *d_steps = nullptr;
-    size_t step_slots = 1;
     LatThr *d_thr_steps = nullptr;
     std::vector<unsigned long long> h_steps;
     std::vector<LatThr> h_thr;
     if (energies_per_step && lattice) {
         // streaming kernels measure inside the colour-1 half-sweep, into MEASURE_SLOTS partial counters per replica
-        step_slots = resident ? 1 : MEASURE_SLOTS;
         TRY(scratch.alloc(&d_steps, chunk * R * 2 * step_slots));
         h_steps.resize(chunk * R * 2 * step_slots);
     }
@@ -1235,10 +1258,16 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
-        // < 64 waves per SIMD per launch: +17..33 % with 2 lanes (4 go host-bound); short calls lose it to fork/join
-        else if (waves_per_launch < 64 * 1024 && timesteps >= 64) want_lanes = 2;
+        // < 64 waves per SIMD per launch: +17..33 % with 2 lanes (4 go host-bound); short calls lose it to fork/join.
+        // Large launches: +2.8 % (one block's drain overlaps the other's ramp); the fork/join is ~45 us per call
+        else if (waves_per_launch < 64 * 1024 ? timesteps >= 64 : timesteps >= 8) want_lanes = 2;
         want_lanes = std::min(want_lanes, R);
     }
+    // every exit path below joins the lanes again: later calls (measure, get_states) use s->stream alone
+    struct LaneJoin {
+        isingmc_states *s;
+        ~LaneJoin() { if (s->n_lanes > 1) (void)lanes_join(s); }
+    } lane_join{s};
     if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
@@ -1404,8 +1433,8 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
-    if (s->packed) {
-        HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
+    if (s->packed) { // counts_slot: [pk_slots()][2], one pair per (group, bit) -- a shard may own only some bits of a group
+        HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * s->pk_slots() * sizeof(unsigned long long), s->stream));
         uint32_t ppt = PK_MEASURE_POS_PER_THREAD; // halved until the launch has >= 1024 workgroups (not below 8: the transpose
                                                   // at the end of a chunk costs as much as ~16 positions)
         while (ppt > 8 && size_t((g->pk.n_pos + 256 * ppt - 1) / (256 * ppt)) * s->groups < 1024) ppt /= 2;
@@ -1413,7 +1442,7 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
             hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
-                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(R - 32 * g0), ppt);
+                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(32 * ng), ppt);
         }
     } else if (g->kind == ISINGMC_KIND_LATTICE2D) {
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));
@@ -1467,29 +1496,30 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
     const bool counts = s->packed || g->kind == ISINGMC_KIND_LATTICE2D;
     const size_t words = s->packed ? s->groups * size_t(g->pk.n_pos) : R * g->state_words;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(S, (size_t(512) << 20) / (words * sizeof(uint32_t))));
+    const size_t CS = s->packed ? s->pk_slots() : R; // counter pairs per sample
     DeviceScratch scratch(s->stream);
     uint32_t *d_samples = nullptr;
     unsigned long long *d_counts = nullptr;
     double *d_e = nullptr;
     long long *d_m = nullptr;
     TRY(scratch.alloc(&d_samples, chunk * words));
-    if (counts) TRY(scratch.alloc(&d_counts, chunk * R * 2));
+    if (counts) TRY(scratch.alloc(&d_counts, chunk * CS * 2));
     else {
         TRY(scratch.alloc(&d_e, chunk * R));
         TRY(scratch.alloc(&d_m, chunk * R));
     }
     std::vector<uint32_t> h_samples(chunk * words);
-    std::vector<unsigned long long> h_counts(counts ? chunk * R * 2 : 0);
+    std::vector<unsigned long long> h_counts(counts ? chunk * CS * 2 : 0);
     std::vector<double> h_e(counts ? 0 : chunk * R);
     for (size_t k0 = 0; k0 < S; k0 += chunk) {
         const size_t nk = std::min(chunk, S - k0);
         for (size_t k = 0; k < nk; k++) {
             TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
             HIP_TRY(hipMemcpyAsync(d_samples + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-            TRY(measure_enqueue(s, counts ? d_counts + k * R * 2 : nullptr, counts ? nullptr : d_e + k * R, counts ? nullptr : d_m + k * R));
+            TRY(measure_enqueue(s, counts ? d_counts + k * CS * 2 : nullptr, counts ? nullptr : d_e + k * R, counts ? nullptr : d_m + k * R));
         }
         HIP_TRY(hipMemcpyAsync(h_samples.data(), d_samples, nk * words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-        if (counts) HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, nk * R * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        if (counts) HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
         else HIP_TRY(hipMemcpyAsync(h_e.data(), d_e, nk * R * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         parallel_for(nk * R, [&](size_t idx) {
@@ -1497,10 +1527,11 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
             uint8_t *out = states_out + (r * S + k0 + k) * N;
             double energy;
             if (s->packed) {
-                const uint32_t *w = h_samples.data() + k * words + (r / 32) * g->pk.n_pos;
-                const uint32_t bit = uint32_t(r % 32);
+                const size_t sl = r + s->pk_bit0;
+                const uint32_t *w = h_samples.data() + k * words + (sl / 32) * g->pk.n_pos;
+                const uint32_t bit = uint32_t(sl % 32);
                 for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
-                energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * R + r) * 2]))) + g->self_energy;
+                energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * CS + sl) * 2]))) + g->self_energy;
             } else {
                 unpack_state(g, h_samples.data() + k * words + r * g->state_words, out);
                 if (counts) energy = g->jabs * double(2 * int64_t(N) - 2 * int64_t(h_counts[(k * R + r) * 2]));
@@ -1641,5 +1672,51 @@ extern "C" int isingmc_pt_state(isingmc_states *s, uint32_t *perm_out, uint64_t 
     if (perm_out) HIP_TRY(hipMemcpy(perm_out, s->d_pt_perm, s->pt.n_rungs * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (round_out) *round_out = c[0];
     if (swaps_out) *swaps_out = c[1];
+    return ISINGMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement hook: the shader clock the chip holds WHILE the sweep kernels run (bench.py reports it next
+// to the vector-ALU bound).  One wave on a side stream stamps s_memtime (shader cycles) and s_memrealtime
+// (100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6) around a sleep loop of `probe_ms`, while `timesteps`
+// sweeps run on the engine's stream.  The probe's exit condition is the constant-rate counter: every wave leaves.
+// ------------------------------------------------------------------------------------------------
+__global__ void clock_probe_kernel(unsigned long long *out, const unsigned long long realtime_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1;
+    do {
+        __builtin_amdgcn_s_sleep(100);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < realtime_ticks);
+    out[0] = __builtin_amdgcn_s_memtime() - c0;
+    out[1] = r1 - r0;
+}
+
+extern "C" int isingmc_debug_shader_clock(isingmc_states *s, size_t timesteps, double beta, double probe_ms, double *ghz_out)
+{
+    if (!s || !ghz_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (!(probe_ms > 0.0) || probe_ms > 100.0) return fail(ISINGMC_ERR_INVALID, "probe_ms must be in (0, 100]");
+    TRY(use_device(s->g->device));
+    DeviceScratch scratch(s->stream);
+    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+    TRY(scratch.alloc(&d_out, 2));
+    struct Side { // a stream of its own: the replica lanes carry sweeps
+        hipStream_t st = nullptr;
+        ~Side() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+    } side_owner;
+    HIP_TRY(hipStreamCreateWithFlags(&side_owner.st, hipStreamNonBlocking));
+    hipStream_t side = side_owner.st;
+    // the sweeps first (they ramp the chip up), then the probe beside them; both are awaited
+    int rc = run_steps(s, timesteps / 4, &beta, 0, nullptr, nullptr, /*sync=*/false);
+    if (rc != ISINGMC_OK) return rc;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, side, d_out, (unsigned long long)(probe_ms * 1e5));
+    HIP_TRY(hipGetLastError());
+    rc = run_steps(s, timesteps - timesteps / 4, &beta, 0, nullptr, nullptr, /*sync=*/true);
+    HIP_TRY(hipStreamSynchronize(side));
+    if (rc != ISINGMC_OK) return rc;
+    HIP_TRY(hipMemcpy(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost));
+    *ghz_out = h_out[1] ? double(h_out[0]) / double(h_out[1]) * 0.1 : 0.0; // cycles per 10 ns tick -> GHz
     return ISINGMC_OK;
 }

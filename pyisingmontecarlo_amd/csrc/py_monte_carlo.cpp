@@ -334,8 +334,8 @@ private:
         auto st = std::make_shared<StatesHandle>();
         st->graph = graph();
         py::gil_scoped_release nogil;
-        check(isingmc_states_create(st->graph->g, hi - lo, seeds.data() + lo,
-                                    initial_state_.empty() ? nullptr : initial_state_.data(), &st->s));
+        check(isingmc_states_create_range(st->graph->g, num_experiments, seeds.data(), lo, hi - lo,
+                                          initial_state_.empty() ? nullptr : initial_state_.data(), &st->s));
         return st;
     }
 

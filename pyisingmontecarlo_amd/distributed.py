@@ -19,9 +19,11 @@ def shard_bounds(n, world, rank):
 
 
 def block_size(n, world):
-    """Replicas per rank: ceil(n / world), rounded up to a multiple of 32 once a rank holds >= 32 of them --
-    the replica-packed general path keys 32-replica groups, so its results are shard-invariant only for
-    blocks that start on a multiple of 32."""
+    """Replicas per rank: ceil(n / world), rounded up to a multiple of 32 once a rank holds >= 32 of them.
+    Results never depend on the cut (isingmc_states_create_range decides everything from the global
+    experiment index; a shard that cuts a 32-replica group of the replica-packed path simulates the whole
+    group), but aligned blocks avoid that duplicated work, and per-replica betas on the packed path
+    (tempering) require them."""
     per = -(-n // world) if world > 0 else n
     return -(-per // 32) * 32 if per >= 32 else per
 

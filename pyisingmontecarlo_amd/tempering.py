@@ -24,8 +24,10 @@ class HipEngine:
         # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream
         self.supports_on_stream_pt = self.graph.kind == _capi.KIND_LATTICE2D
 
-    def make_states(self, seeds):
-        return _capi.States(self.graph, seeds)
+    def make_states(self, seeds, replica_range=None):
+        """seeds of ALL slots + this rank's [lo, hi): group membership on the replica-packed path follows the global
+        slot index, so the ladder's trajectories do not depend on the number of ranks."""
+        return _capi.States(self.graph, seeds, replica_range=replica_range)
 
 
 def _split(edges):
@@ -114,7 +116,7 @@ class ClassicalTempering:
         self._per = D.block_size(G, self._world)
         self._lo, self._hi = D.shard_bounds(G, self._world, self._rank)
         self._engine = self._engine_factory()
-        self._states = self._engine.make_states(np.array(self._slot_seeds[self._lo:self._hi], dtype=np.uint64))
+        self._states = self._engine.make_states(np.array(self._slot_seeds, dtype=np.uint64), (self._lo, self._hi))
         self._perm = np.arange(G, dtype=np.uint32)
         self._on_stream = bool(getattr(self._engine, "supports_on_stream_pt", False)) and self._hi > self._lo
         if self._world > 1:  # every rank must take the same path (the collective differs)

@@ -48,5 +48,6 @@ class OracleLatEngine:
         self.lat = O.Lat(W, H, jabs, jpos)
         self.nvars = W * H
 
-    def make_states(self, seeds):
-        return OracleLatStates(self.lat, seeds)
+    def make_states(self, seeds, replica_range=None):
+        lo, hi = replica_range if replica_range is not None else (0, len(seeds))
+        return OracleLatStates(self.lat, seeds[lo:hi])

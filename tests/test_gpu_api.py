@@ -142,6 +142,50 @@ def test_replica_range_is_shard_invariant(mod, exact):
         lat.run_monte_carlo(0.4407, 1, 8, replica_range=(5, 9))
 
 
+def test_replica_range_is_shard_invariant_on_packed_general_graphs(mod, capi, oracle, exact):
+    """the replica-packed general path groups 32 replicas (shared Philox words, ties numbered over the
+    group).  Group, key and bit follow the GLOBAL experiment index, so 64 experiments cut 4 x 16, 8 x 8 or
+    unevenly give the arrays of the unsharded call -- which match oracle engine D."""
+    W = H = 120                                                    # 14 400 sites, not 64-wide: general, above the resident bound
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=3)
+    assert lat.engine_info()["kind"] == "general"
+    R, T, beta = 64, 4, 0.42
+    e, s = lat.run_monte_carlo(beta, T, R)
+    e_ref, s_ref = oracle.pk_run(ea, eb, ej, W * H, np.array(lat.make_seeds(R), dtype=np.uint64), T, betas=[beta] * T)
+    assert np.array_equal(s, s_ref[:R].astype(bool)) and np.array_equal(e, e_ref)
+    for cuts in ([(16 * k, 16 * k + 16) for k in range(4)], [(8 * k, 8 * k + 8) for k in range(8)],
+                 [(0, 5), (5, 37), (37, 64)]):
+        parts = [lat.run_monte_carlo(beta, T, R, replica_range=r) for r in cuts]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), e), cuts
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), s), cuts
+    # per-step energies and sampling through a shard that owns bits 5..36 of two groups
+    betas = [(0, 0.2), (T, 0.6)]
+    ea_full, _ = lat.run_monte_carlo_annealing_and_get_energies(betas, T, R)
+    ea_part, _ = lat.run_monte_carlo_annealing_and_get_energies(betas, T, R, replica_range=(5, 37))
+    assert np.array_equal(ea_part, ea_full[5:37])
+    es_full, ss_full = lat.run_monte_carlo_sampling(beta, 4, R, None, 1, 2)
+    es_part, ss_part = lat.run_monte_carlo_sampling(beta, 4, R, None, 1, 2, replica_range=(5, 37))
+    assert np.array_equal(es_part, es_full[5:37]) and np.array_equal(ss_part, ss_full[5:37])
+    # per-replica betas need whole groups
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(3, R)
+    st = capi.States(g, seeds, replica_range=(5, 37))
+    with pytest.raises(ValueError, match="multiple of 32"):
+        st.set_betas(np.full(32, 0.3))
+    whole = capi.States(g, seeds)
+    whole.set_betas(np.linspace(0.1, 1.0, R))
+    whole.do_time_steps(3)
+    half = capi.States(g, seeds, replica_range=(32, 64))
+    half.set_betas(np.linspace(0.1, 1.0, R)[32:])
+    half.do_time_steps(3)
+    assert np.array_equal(half.states(), whole.states()[32:]) and np.array_equal(half.energies(), whole.energies()[32:])
+    # fewer than 16 experiments in the shard, 64 in total: still the packed trajectories, not the per-replica CSR ones
+    few = capi.States(g, seeds, replica_range=(60, 64))
+    few.do_time_steps(T, beta)
+    assert np.array_equal(few.states(), s[60:64])
+
+
 def test_classic_ising_persistent(mod, oracle, exact):
     W, H = 64, 8
     ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)

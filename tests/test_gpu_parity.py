@@ -412,3 +412,76 @@ def test_large_launch_takes_the_looping_kernel_bit_exact(capi, oracle, exact, gl
             lat.sweep(ref, seeds[r], t, beta)
         np.testing.assert_array_equal(packed[r], ref, err_msg=f"replica {r}")
         assert energies[r] == lat.energy_mag(ref)[0]
+
+
+# ---- round 2: the three lattice-kernel branches that had no oracle comparison ----------
+
+def test_per_step_energies_many_workgroups_per_replica(capi, oracle, exact):
+    """lat_sweep_measure_kernel with 32 workgroups per replica (4096 x 512: 8192 quads per colour): the 16 counter
+    slots per replica are each hit twice and summed on the host -- energies after every timestep
+    (lattice.rs:445-455) and the final configuration against the oracle, +-J couplings."""
+    W, H, T, beta = 4096, 512, 3, 0.7
+    ea, eb, ej = exact.square_lattice_edges(W, H, 1.0, np.random.default_rng(12))
+    g = capi.Graph(ea, eb, ej)
+    assert g.kind == capi.KIND_LATTICE2D and not g.info.uniform_sign
+    seeds = SEEDS[:2]
+    st = capi.States(g, seeds)
+    eps = st.do_time_steps(T, beta, per_step_energies=True)
+    lat = oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8))
+    packed = st.packed()
+    for r, s in enumerate(seeds):
+        ref = lat.init(s)
+        for t in range(T):
+            lat.sweep(ref, s, t, beta)
+            assert eps[r, t] == lat.energy_mag(ref)[0], (r, t)
+        np.testing.assert_array_equal(packed[r], ref)
+
+
+def test_per_step_energies_2048_square_vs_separate_measurement(capi, oracle, exact):
+    """BASELINE c4's geometry (2048^2: 64 workgroups per replica, every counter slot hit 4x): the fused per-step
+    energies equal lat_measure_kernel's after single steps, and K1 (host recomputation from the returned spins)."""
+    L, T = 2048, 3
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = SEEDS[:2]
+    betas = np.array([0.3, 0.4407, 0.6])
+    a = capi.States(g, seeds)
+    eps = a.do_time_steps(T, betas, per_step_energies=True)
+    b = capi.States(g, seeds)
+    for t in range(T):
+        b.do_time_steps(1, float(betas[t]))
+        np.testing.assert_array_equal(eps[:, t], b.energies(), err_msg=f"step {t}")
+    np.testing.assert_array_equal(a.packed(), b.packed())
+    spins = a.states()
+    for r in range(2):
+        assert eps[r, T - 1] == oracle.energy(ea, eb, ej, L * L, spins[r])
+
+
+def test_streaming_kernel_rows_of_16384_bit_exact(capi, oracle, exact):
+    """W = 16384: 64 quads per row, a wavefront never leaves its row (the cl >= 6 branch of load_quad_uni);
+    H = 64 gives 4096 quads per colour, too many for the LDS-resident kernel."""
+    st = _lattice_case(capi, oracle, exact, 16384, 64, -1.0, 0.4407, T=3, per_step=False)
+    assert st.graph.info.width == 16384
+    _lattice_case(capi, oracle, exact, 16384, 64, 1.0, 0.8, T=2, rng=np.random.default_rng(3), per_step=True)
+
+
+def test_looping_kernel_at_headline_width_bit_exact(capi, oracle, exact):
+    """lat_sweep_loop_kernel<uniform J> at the headline geometry W = 4096 (cols_log2 = 4): 4096 x 128 x 2048
+    replicas = 4 workgroups of quad pairs per replica (2048 quads per colour: not LDS-resident), enough
+    workgroups for the host to choose the looping kernel with or without replica lanes."""
+    W, H, R, T, beta = 4096, 128, 2048, 3, 0.4407
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.uniform_sign
+    seeds = capi.make_seeds(4096, R)
+    st = capi.States(g, seeds)
+    st.do_time_steps(T, beta)
+    packed = st.packed()
+    energies = st.energies()
+    lat = oracle.Lat(W, H, 1.0, 0)
+    for r in (0, 1023, 1024, R - 1):
+        ref = lat.init(seeds[r])
+        for t in range(T):
+            lat.sweep(ref, seeds[r], t, beta)
+        np.testing.assert_array_equal(packed[r], ref, err_msg=f"replica {r}")
+        assert energies[r] == lat.energy_mag(ref)[0]
