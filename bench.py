@@ -104,13 +104,13 @@ def traffic_from_profile():
 def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
     """Secondary roofline: the sweep kernel is bound by vector-ALU issue cycles, not by HBM.
     achieved = VALU-busy SIMD cycles per quad (SQ counters of the same kernel, committed under profiles/);
-    peak = SIMD cycles a quad owns = launch time x live shader clock x SIMDs / quads per launch."""
+    peak = SIMD cycles a wave of quads owns = launch time x live shader clock x SIMDs / wave-quads per launch."""
     d = _profile_json("sq_latest.json")
     if not d or not clock_ghz:
         return None
     owned = avg_launch_us * 1e-6 * clock_ghz * 1e9 * N_CU * SIMD_PER_CU / quads_per_launch
     busy = d["valu_busy_cycles_per_quad"]
-    return {"bound": "valu", "achieved": busy, "peak": owned, "unit": "SIMD cycles per quad (128 spins)",
+    return {"bound": "valu", "achieved": busy, "peak": owned, "unit": "SIMD cycles per wave of 64 quads (8192 spins)",
             "frac": busy / owned, "clock_ghz": clock_ghz, "valu_insts_per_quad": d.get("valu_insts_per_quad"),
             "source": d.get("source")}
 
@@ -197,7 +197,7 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_launch_us,
                     "launch": "one colour half-sweep of all replicas (2 kernel dispatches, one per lane)"}
-        sec = valu_bound(avg_launch_us, clock_ghz, R * nvars / 2 / 128)
+        sec = valu_bound(avg_launch_us, clock_ghz, R * nvars / 2 / 128 / 64)  # wave-quads: 64 lanes x 128 spins
         if sec:
             roofline["secondary"] = sec
         out = {

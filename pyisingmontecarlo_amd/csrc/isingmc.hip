@@ -729,7 +729,15 @@ extern "C" uint64_t isingmc_states_timestep(const isingmc_states *s) { return s 
 
 extern "C" void isingmc_states_destroy(isingmc_states *s) { delete s; }
 
+static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal);
+
 extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_per_replica)
+{
+    return set_betas(s, beta_per_replica, false);
+}
+
+// all_equal: the caller passes one beta R times (run_sampling) -- then a shard that cuts a replica group is fine
+static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (!beta_per_replica) {
@@ -740,7 +748,7 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
     for (size_t r = 0; r < s->R; r++)
         if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
-    if (s->packed && s->pk_bit0 != 0)
+    if (s->packed && s->pk_bit0 != 0 && !all_equal)
         // the replicas of a group number their ties together: a group's trajectory depends on all 32 betas, and this
         // shard only knows its own
         return fail(ISINGMC_ERR_INVALID, "per-replica betas on a replica-packed shard: the shard must start on a multiple of 32 experiments");
@@ -1484,7 +1492,7 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
     } guard{s, false};
     if (!s->has_betas && R) {
         const std::vector<double> b(R, beta);
-        TRY(isingmc_states_set_betas(s, b.data()));
+        TRY(set_betas(s, b.data(), /*all_equal=*/true));
         guard.active = true;
     }
     TRY(run_steps(s, thermalization, nullptr, 0, nullptr, nullptr, /*sync=*/false));

@@ -14,6 +14,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "isingmc.h"
@@ -41,6 +42,33 @@ int default_device()
         if (isingmc_device_count(&count) == ISINGMC_OK && std::atoi(lr) < count) return std::atoi(lr);
     }
     return 0;
+}
+
+// ISINGMC_DEVICES=0,1,...: the devices Lattice.run_monte_carlo* fans its experiments out over (one host thread and
+// one isingmc_states per entry; an ordinal may repeat).  Unset: the one device of default_device().
+std::vector<int> default_devices()
+{
+    std::vector<int> out;
+    if (const char *e = std::getenv("ISINGMC_DEVICES")) {
+        const std::string str(e);
+        size_t pos = 0;
+        while (pos <= str.size()) {
+            const size_t comma = std::min(str.find(',', pos), str.size());
+            const std::string tok = str.substr(pos, comma - pos);
+            if (!tok.empty()) {
+                if (tok == "all") {
+                    int count = 0;
+                    if (isingmc_device_count(&count) == ISINGMC_OK)
+                        for (int d = 0; d < count; d++) out.push_back(d);
+                } else {
+                    out.push_back(std::atoi(tok.c_str()));
+                }
+            }
+            pos = comma + 1;
+        }
+    }
+    if (out.empty()) out.push_back(default_device());
+    return out;
 }
 
 bool compat_anneal_bug()
@@ -124,7 +152,7 @@ class Lattice {
 public:
     Lattice(const py::object &edges, std::optional<uint64_t> seed_gen, std::optional<bool> use_allocator)
         : E_(std::make_shared<EdgeArrays>(split_edges(edges))), seed_gen_(seed_gen),
-          use_allocator_(use_allocator.value_or(true)), device_(default_device())
+          use_allocator_(use_allocator.value_or(true)), devices_(default_devices())
     {
         if (E_->a.empty()) throw py::value_error("Must supply some edges for graph"); // lattice.rs:70-72
     }
@@ -146,7 +174,7 @@ public:
         for (ssize_t k = 0; k < a.size(); k++) E->nvars = std::max<size_t>(E->nvars, std::max(E->a[k], E->b[k]) + 1);
         L.E_ = E;
         L.seed_gen_ = seed_gen;
-        L.device_ = default_device();
+        L.devices_ = default_devices();
         return L;
     }
 
@@ -169,14 +197,14 @@ public:
                                   std::to_string(E_->nvars));
         if (biases_.empty()) biases_.assign(E_->nvars, global_bias_);
         biases_[var] = bias;
-        graph_.reset();
+        graphs_.clear();
     }
 
     void set_global_bias(double bias) // lattice.rs:129-131
     {
         biases_.clear();
         global_bias_ = bias;
-        graph_.reset();
+        graphs_.clear();
     }
 
     void set_transverse_field(double transverse) // lattice.rs:134-146
@@ -194,8 +222,15 @@ public:
     }
 
     // extensions: device ordinal, and forcing the general edge-list path (BASELINE config c5)
-    void set_device(int device) { device_ = device; graph_.reset(); }
-    void set_force_general_path(bool v) { force_general_ = v; graph_.reset(); }
+    void set_device(int device) { devices_ = {device}; graphs_.clear(); }
+    void set_devices(const std::vector<int> &devices) // extension: the device list of the in-process fan-out
+    {
+        if (devices.empty()) throw py::value_error("the device list must not be empty");
+        devices_ = devices;
+        graphs_.clear();
+    }
+    std::vector<int> get_devices() const { return devices_; }
+    void set_force_general_path(bool v) { force_general_ = v; graphs_.clear(); }
     py::dict engine_info()
     {
         isingmc_graph_info_t info;
@@ -216,16 +251,18 @@ public:
                               std::optional<bool>, Range replica_range)
     {
         require_classical();
-        auto st = fresh_states(num_experiments, replica_range);
-        const size_t R = count(st);
+        const auto [lo, hi] = bounds(num_experiments, replica_range);
+        const size_t R = hi - lo, N = E_->nvars;
         py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R)});
-        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
-        {
-            py::gil_scoped_release nogil;
-            check(isingmc_do_time_steps(st->s, timesteps, &beta, 0, nullptr));
-            check(isingmc_get_energies(st->s, energies.mutable_data()));
-            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
-        }
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(N)});
+        double *e = energies.mutable_data();
+        uint8_t *st = reinterpret_cast<uint8_t *>(states.mutable_data());
+        fan_out(num_experiments, lo, hi, [&](isingmc_states *s, size_t off) {
+            int rc = isingmc_do_time_steps(s, timesteps, &beta, 0, nullptr);
+            if (rc == ISINGMC_OK) rc = isingmc_get_energies(s, e + off);
+            if (rc == ISINGMC_OK) rc = isingmc_get_states(s, st + off * N, N);
+            return rc;
+        });
         return py::make_tuple(energies, states);
     }
 
@@ -238,15 +275,16 @@ public:
         const size_t therm = thermalization_time.value_or(0), freq = sampling_freq.value_or(1);
         if (freq == 0) throw py::value_error("sampling_freq must be positive");
         const size_t S = timesteps / freq; // lattice.rs:247
-        auto st = fresh_states(num_experiments, replica_range);
-        const size_t R = count(st), N = E_->nvars;
+        const auto [lo, hi] = bounds(num_experiments, replica_range);
+        const size_t R = hi - lo, N = E_->nvars;
         py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(S)});
         py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(S), ssize_t(N)});
-        {
-            py::gil_scoped_release nogil;
-            sample_into(st->s, beta, therm, freq, S, R, N, energies.mutable_data(),
-                        reinterpret_cast<uint8_t *>(states.mutable_data()));
-        }
+        double *e = energies.mutable_data();
+        uint8_t *st = reinterpret_cast<uint8_t *>(states.mutable_data());
+        // lattice.rs:271-287: thermalise, then S x { freq steps; record state + energy } -- one library call per shard
+        fan_out(num_experiments, lo, hi, [&](isingmc_states *s, size_t off) {
+            return isingmc_run_sampling(s, beta, therm, freq, S, e + off * S, st + off * S * N);
+        });
         return py::make_tuple(energies, states);
     }
 
@@ -257,16 +295,18 @@ public:
     {
         require_classical();
         const std::vector<double> schedule = expand(betas, timesteps);
-        auto st = fresh_states(num_experiments, replica_range);
-        const size_t R = count(st);
+        const auto [lo, hi] = bounds(num_experiments, replica_range);
+        const size_t R = hi - lo, N = E_->nvars;
         py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R)});
-        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
-        {
-            py::gil_scoped_release nogil;
-            check(isingmc_do_time_steps(st->s, timesteps, schedule.data(), 1, nullptr));
-            check(isingmc_get_energies(st->s, energies.mutable_data()));
-            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
-        }
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(N)});
+        double *e = energies.mutable_data();
+        uint8_t *st = reinterpret_cast<uint8_t *>(states.mutable_data());
+        fan_out(num_experiments, lo, hi, [&](isingmc_states *s, size_t off) {
+            int rc = isingmc_do_time_steps(s, timesteps, schedule.data(), 1, nullptr);
+            if (rc == ISINGMC_OK) rc = isingmc_get_energies(s, e + off);
+            if (rc == ISINGMC_OK) rc = isingmc_get_states(s, st + off * N, N);
+            return rc;
+        });
         return py::make_tuple(energies, states);
     }
 
@@ -277,15 +317,17 @@ public:
     {
         require_classical();
         const std::vector<double> schedule = expand(betas, timesteps);
-        auto st = fresh_states(num_experiments, replica_range);
-        const size_t R = count(st);
+        const auto [lo, hi] = bounds(num_experiments, replica_range);
+        const size_t R = hi - lo, N = E_->nvars;
         py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(timesteps)});
-        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(E_->nvars)});
-        {
-            py::gil_scoped_release nogil;
-            check(isingmc_do_time_steps(st->s, timesteps, schedule.data(), 1, energies.mutable_data()));
-            check(isingmc_get_states(st->s, reinterpret_cast<uint8_t *>(states.mutable_data()), E_->nvars));
-        }
+        py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(N)});
+        double *e = energies.mutable_data();
+        uint8_t *st = reinterpret_cast<uint8_t *>(states.mutable_data());
+        fan_out(num_experiments, lo, hi, [&](isingmc_states *s, size_t off) {
+            int rc = isingmc_do_time_steps(s, timesteps, schedule.data(), 1, e + off * timesteps);
+            if (rc == ISINGMC_OK) rc = isingmc_get_states(s, st + off * N, N);
+            return rc;
+        });
         return py::make_tuple(energies, states);
     }
 
@@ -308,38 +350,71 @@ private:
             throw py::value_error("Cannot run classic monte carlo with transverse field");
     }
 
-    std::shared_ptr<GraphHandle> graph()
+    // one graph per entry of the device list, built on first use (the first one serves engine_info)
+    std::shared_ptr<GraphHandle> graph(size_t slot = 0)
     {
-        if (!graph_) {
+        if (graphs_.size() != devices_.size()) graphs_.assign(devices_.size(), nullptr);
+        if (!graphs_[slot]) {
             std::vector<double> b;
             const std::vector<double> *bp = nullptr;
             if (!biases_.empty()) bp = &biases_;
             else if (global_bias_ != 0.0) { b.assign(E_->nvars, global_bias_); bp = &b; } // lattice.rs:186-189
-            graph_ = make_graph(*E_, bp, device_, force_general_);
+            graphs_[slot] = make_graph(*E_, bp, devices_[slot], force_general_);
         }
-        return graph_;
+        return graphs_[slot];
     }
 
-    // R x { seed -> rng; GraphState::new; set_state(initial) }  (lattice.rs:191-203).  replica_range
-    // (extension) keeps only experiments [lo, hi) of the num_experiments seeds: one shard per GPU/rank.
-    std::shared_ptr<StatesHandle> fresh_states(size_t num_experiments, const Range &range)
+    static std::pair<size_t, size_t> bounds(size_t num_experiments, const Range &range)
     {
-        std::vector<uint64_t> seeds = make_seeds(num_experiments);
-        size_t lo = 0, hi = num_experiments;
-        if (range) {
-            lo = range->first;
-            hi = range->second;
-            if (lo > hi || hi > num_experiments) throw py::value_error("replica_range out of bounds");
-        }
-        auto st = std::make_shared<StatesHandle>();
-        st->graph = graph();
-        py::gil_scoped_release nogil;
-        check(isingmc_states_create_range(st->graph->g, num_experiments, seeds.data(), lo, hi - lo,
-                                          initial_state_.empty() ? nullptr : initial_state_.data(), &st->s));
-        return st;
+        if (!range) return {0, num_experiments};
+        if (range->first > range->second || range->second > num_experiments) throw py::value_error("replica_range out of bounds");
+        return {range->first, range->second};
     }
 
-    static size_t count(const std::shared_ptr<StatesHandle> &st) { return isingmc_states_count(st->s); }
+    // The rayon fan-out of lattice.rs:192-197, over devices: experiments [lo, hi) are cut into contiguous blocks,
+    // one per entry of the device list (ISINGMC_DEVICES / set_devices; aligned to 32 experiments once a block
+    // holds that many), and every block runs on its device from a host thread of its own:
+    //   seed -> rng; GraphState::new; set_state(initial)  (lattice.rs:198-203) = isingmc_states_create_range,
+    // then body(states, offset of the block in the output arrays).  Philox keys, replica groups and the path
+    // choice follow the GLOBAL experiment index, so the arrays do not depend on the device list.
+    template <typename Body>
+    void fan_out(size_t num_experiments, size_t lo, size_t hi, Body &&body)
+    {
+        const std::vector<uint64_t> seeds = make_seeds(num_experiments);
+        const size_t n = hi - lo, D = devices_.size();
+        size_t per = (n + D - 1) / std::max<size_t>(D, 1);
+        if (per >= 32) per = (per + 31) / 32 * 32;
+        struct Block { size_t slot, lo, hi; int rc = ISINGMC_OK; std::string msg; };
+        std::vector<Block> blocks;
+        for (size_t d = 0; d < D; d++) {
+            const size_t b = std::min(hi, lo + d * per), e = std::min(hi, b + per);
+            if (e > b || (d == 0 && n == 0)) blocks.push_back({d, b, e});
+        }
+        for (const Block &blk : blocks) (void)graph(blk.slot); // may raise: with the GIL, before any thread starts
+        const uint8_t *ini = initial_state_.empty() ? nullptr : initial_state_.data();
+        const auto run_block = [&](Block &blk) {
+            isingmc_states *st = nullptr;
+            blk.rc = isingmc_states_create_range(graphs_[blk.slot]->g, num_experiments, seeds.data(), blk.lo, blk.hi - blk.lo, ini, &st);
+            if (blk.rc == ISINGMC_OK) blk.rc = body(st, blk.lo - lo);
+            if (blk.rc != ISINGMC_OK) blk.msg = isingmc_last_error(); // per thread: read it where it was set
+            isingmc_states_destroy(st);
+        };
+        {
+            py::gil_scoped_release nogil;
+            if (blocks.size() == 1) run_block(blocks[0]);
+            else {
+                std::vector<std::thread> pool;
+                for (Block &blk : blocks) pool.emplace_back([&run_block, &blk] { run_block(blk); });
+                for (auto &th : pool) th.join();
+            }
+        }
+        for (const Block &blk : blocks) {
+            if (blk.rc == ISINGMC_OK) continue;
+            if (blk.rc == ISINGMC_ERR_INVALID) throw py::value_error(blk.msg);
+            if (blk.rc == ISINGMC_ERR_ALLOC) throw std::bad_alloc();
+            throw std::runtime_error(blk.msg);
+        }
+    }
 
     static std::vector<double> expand(const std::vector<std::pair<size_t, double>> &betas, size_t timesteps)
     {
@@ -359,9 +434,9 @@ private:
     bool enable_rvb_ = false, enable_heatbath_ = false;
     std::optional<uint64_t> seed_gen_;
     bool use_allocator_ = true;
-    int device_ = 0;
+    std::vector<int> devices_;  // one block of experiments per entry (ISINGMC_DEVICES; an ordinal may repeat)
     bool force_general_ = false;
-    std::shared_ptr<GraphHandle> graph_;
+    std::vector<std::shared_ptr<GraphHandle>> graphs_;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -487,6 +562,8 @@ PYBIND11_MODULE(_py_monte_carlo, m)
         .def("set_transverse_field", &Lattice::set_transverse_field, "transverse"_a)
         .def("set_initial_state", &Lattice::set_initial_state, "initial_state"_a)
         .def("set_device", &Lattice::set_device, "device"_a)
+        .def("set_devices", &Lattice::set_devices, "devices"_a)
+        .def("get_devices", &Lattice::get_devices)
         .def("set_force_general_path", &Lattice::set_force_general_path, "force"_a)
         .def("engine_info", &Lattice::engine_info)
         .def("run_monte_carlo", &Lattice::run_monte_carlo, "beta"_a, "timesteps"_a, "num_experiments"_a,

@@ -186,6 +186,39 @@ def test_replica_range_is_shard_invariant_on_packed_general_graphs(mod, capi, or
     assert np.array_equal(few.states(), s[60:64])
 
 
+@pytest.mark.parametrize("kind", ["lattice", "packed_general"])
+def test_in_process_device_fan_out_equals_single_device(mod, exact, monkeypatch, kind):
+    """The rayon fan-out of lattice.rs:192-197 over the device list (ISINGMC_DEVICES / set_devices: one host
+    thread + one isingmc_states per entry).  The list 0,0 runs two blocks side by side on the one GPU here;
+    all four run_* methods must return the arrays of the single-device call."""
+    if kind == "lattice":
+        ea, eb, ej = exact.square_lattice_edges(256, 64, -1.0, np.random.default_rng(1))
+    else:
+        ea, eb, ej = exact.square_lattice_edges(120, 120, -1.0)
+    one = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=11)
+    assert one.get_devices() == [0]
+    monkeypatch.setenv("ISINGMC_DEVICES", "0,0,0")
+    many = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=11)
+    assert many.get_devices() == [0, 0, 0]
+    R, T = 70, 6                                                   # blocks 32 + 32 + 6
+    stops = [(0, 0.2), (T, 0.7)]
+    for call in (lambda l: l.run_monte_carlo(0.44, T, R),
+                 lambda l: l.run_monte_carlo_annealing(stops, T, R),
+                 lambda l: l.run_monte_carlo_annealing_and_get_energies(stops, T, R),
+                 lambda l: l.run_monte_carlo_sampling(0.44, T, R, None, 2, 3),
+                 lambda l: l.run_monte_carlo(0.44, T, R, replica_range=(9, 50)),
+                 lambda l: l.run_monte_carlo(0.44, T, 2),          # fewer experiments than devices
+                 lambda l: l.run_monte_carlo(0.44, T, 0)):
+        a, b = call(one), call(many)
+        assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    many.set_devices([0, 99])                                      # a block that fails reports, nothing hangs
+    with pytest.raises(RuntimeError):
+        many.run_monte_carlo(0.44, 2, 8)
+    with pytest.raises(ValueError):
+        many.set_devices([])
+
+
 def test_classic_ising_persistent(mod, oracle, exact):
     W, H = 64, 8
     ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)

@@ -1,0 +1,54 @@
+"""Multi-GPU: the real RCCL collective of the tempering swap step (needs >= 2 GPUs; skips cleanly on a one-GPU box)
+and a bare `python bench.py --gpus 2` rehearsed on one GPU with the gloo backend."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()      # does not initialise the GPU on this image
+
+
+def test_on_stream_tempering_over_rccl_two_gpus(tmp_path):
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs: the nccl (RCCL) all-gather under torch.cuda.ExternalStream")
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_nccl_worker.py"), out]
+    assert subprocess.call(cmd, env=env, timeout=900) == 0
+    res = [json.load(open(out + f".{r}")) for r in range(2)]
+    for r in res:
+        assert r["perm"] == res[0]["solo_perm"] and r["swaps"] == res[0]["solo_swaps"] > 0
+        assert r["gathered"] == [0.5, 1.5, 2.5, 3.5, 4.5, 0.0]
+    assert res[0]["energies"] + res[1]["energies"] == res[0]["solo_energies"]
+
+
+def test_bare_bench_invocation_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's form): the parent starts the
+    ranks itself and rank 0 prints the one JSON line with n_gpus = 2.  gloo backend: both ranks share this box's GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--replicas", "8", "--precondition-s", "0.05", "--backend", "gloo"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and "cpu_baseline" not in rec and -1.6 < rec["energy_per_site"] < 0.0
