@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "host_logic.hpp"
 #include "lattice_kernels.hpp"
 #include "packed_kernels.hpp"
+#include "strip_kernels.hpp"
 
 using namespace isingmc;
 
@@ -111,6 +113,12 @@ struct isingmc_states {
     size_t pk_bit0 = 0; // replica r of this shard is bit (r + pk_bit0) % 32 of group (r + pk_bit0) / 32 (shards cut GLOBAL groups)
     size_t pk_slots() const { return 32 * groups; } // counter slots: one per (group, bit), owned or not
     uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
+    // persistent strip kernel (strip_kernels.hpp): halo granules, error word, tag epoch
+    unsigned long long *d_halo = nullptr;
+    size_t halo_cap = 0; // granules allocated
+    uint32_t *d_strip_err = nullptr;
+    uint32_t strip_epoch = 0;
+    bool meas_fresh = false; // d_meas holds the counts of the CURRENT configurations (fused into the last strip launch)
     // on-stream parallel tempering (isingmc_pt_*)
     bool pt_attached = false;
     PtDev pt{};
@@ -128,6 +136,8 @@ struct isingmc_states {
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
         if (d_tab) (void)hipFree(d_tab);
+        if (d_halo) (void)hipFree(d_halo);
+        if (d_strip_err) (void)hipFree(d_strip_err);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
                         (void *)d_pt_counters})
             if (p) (void)hipFree(p);
@@ -603,6 +613,7 @@ static int init_random(isingmc_states *s, size_t first, size_t count)
 
 static int upload_state(isingmc_states *s, size_t first, size_t count, const uint8_t *spins)
 {
+    s->meas_fresh = false;
     std::vector<uint32_t> words(s->g->state_words);
     pack_state(s->g, spins, words.data());
     for (size_t r = first; r < first + count; r++)
@@ -1209,8 +1220,119 @@ static bool resident_disabled()
     return e && e[0] && e[0] != '0';
 }
 
+// ------------------------------------------------------------------------------------------------
+// persistent strip kernel (strip_kernels.hpp): when and how
+// ------------------------------------------------------------------------------------------------
+struct StripPlan {
+    bool use = false;
+    StripArgs a{};
+    size_t replicas_per_pass = 0; // a pass = one launch over a block of replicas for all timesteps of the chunk
+};
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = std::getenv(name);
+    return e && e[0] ? std::atoi(e) : dflt;
+}
+
+// Mid-size lattices only: a per-colour launch of the streaming kernel must be short enough for the ~5 us it loses
+// between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups per launch, default 2 x the resident
+// limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
+// half-sweep must fit one workgroup (2 rows of <= 128 words).  ISINGMC_STRIP=0 disables, =1 forces (tests, A/B runs).
+static StripPlan strip_plan(const isingmc_states *s, size_t timesteps)
+{
+    StripPlan P;
+    const isingmc_graph *g = s->g;
+    const int mode = env_int("ISINGMC_STRIP", -1);
+    if (mode == 0 || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
+    const uint32_t qpr = g->geom.wpr / 4;
+    if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, 2 * wpr <= 256 polling lanes
+    const uint32_t S = 256 / qpr;
+    if (g->geom.H % S != 0 || g->geom.H / S < 2) return P;
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
+    const size_t limit = size_t(STRIP_MAX_WG_PER_CU) * size_t(std::max(dev_cus, 1));
+    const size_t n_strips = g->geom.H / S, total = s->R * n_strips;
+    if (n_strips > limit) return P;
+    if (mode != 1 && total > size_t(env_int("ISINGMC_STRIP_MAX_WG", int(2 * limit)))) return P;
+    const size_t passes = (total + limit - 1) / limit;
+    P.replicas_per_pass = (s->R + passes - 1) / passes;
+    while (P.replicas_per_pass * n_strips > limit) P.replicas_per_pass--;
+    if (P.replicas_per_pass == 0) return P;
+    P.a.S = S;
+    P.a.n_strips = uint32_t(n_strips);
+    uint32_t ql = 0;
+    while ((1u << ql) < qpr) ql++;
+    P.a.qpr_log2 = ql;
+    P.use = true;
+    return P;
+}
+
+// strip launches of one process on one device never overlap: each needs all its workgroups resident at once
+static std::mutex g_strip_mutex;
+static hipEvent_t g_strip_done[64] = {};
+
+// one pass: replicas [r0, r0 + n) for timesteps [s->t, s->t + nk).  steps_out / final_out: see lat_strip_kernel
+static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t n, size_t nk, const LatThr *d_thr_steps,
+                        uint32_t thr_stride, unsigned long long *steps_out, unsigned long long *final_out)
+{
+    const isingmc_graph *g = s->g;
+    const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
+    if (s->halo_cap < granules) {
+        if (s->d_halo) HIP_TRY(hipFree(s->d_halo));
+        s->d_halo = nullptr;
+        s->halo_cap = 0;
+        TRY(dev_alloc(&s->d_halo, granules));
+        HIP_TRY(hipMemsetAsync(s->d_halo, 0, granules * sizeof(unsigned long long), s->stream));
+        s->halo_cap = granules;
+        s->strip_epoch = 0;
+    }
+    if (!s->d_strip_err) {
+        TRY(dev_alloc(&s->d_strip_err, 4));
+        HIP_TRY(hipMemsetAsync(s->d_strip_err, 0, 4 * sizeof(uint32_t), s->stream));
+    }
+    if (uint64_t(s->strip_epoch) + 2 * nk + 2 >= 0xFFFFFFF0ull) { // tags are unique per states object: restart them
+        HIP_TRY(hipMemsetAsync(s->d_halo, 0, s->halo_cap * sizeof(unsigned long long), s->stream));
+        s->strip_epoch = 0;
+    }
+    StripArgs a = P.a;
+    a.epoch = s->strip_epoch;
+    a.xcd_remap = n % 8 == 0;
+    const size_t lds = (size_t(2) * (a.S + 2) * g->geom.wpr + 16) * sizeof(uint32_t);
+    {
+        std::lock_guard<std::mutex> lock(g_strip_mutex);
+        hipEvent_t &ev = g_strip_done[g->device & 63];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(s->stream, ev, 0));
+        const auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(unsigned(n * a.n_strips)), dim3(256), lds, s->stream, s->d_state + r0 * g->state_words,
+                               g->geom, a, s->t, uint32_t(nk), s->d_keys + r0, d_thr_steps, thr_stride,
+                               s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform,
+                               s->d_halo + r0 * size_t(a.n_strips) * 4 * g->geom.wpr, steps_out, final_out, uint32_t(s->R),
+                               s->d_strip_err);
+        };
+        if (g->uniform_sign) launch(lat_strip_kernel<false>); else launch(lat_strip_kernel<true>);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev, s->stream));
+    }
+    return ISINGMC_OK;
+}
+
+// after a synchronisation: did a strip launch give up (its workgroups were not all resident)?
+static int strip_check(isingmc_states *s)
+{
+    if (!s->d_strip_err) return ISINGMC_OK;
+    uint32_t h = 0;
+    HIP_TRY(hipMemcpy(&h, s->d_strip_err, sizeof h, hipMemcpyDeviceToHost));
+    if (h == 0) return ISINGMC_OK;
+    (void)hipMemset(s->d_strip_err, 0, sizeof h);
+    return fail(ISINGMC_ERR_HIP, "the persistent strip kernel timed out waiting for a neighbour strip (its workgroups were not all "
+                                 "resident: is another process using this GPU?); the configurations of this object are invalid. "
+                                 "ISINGMC_STRIP=0 selects the per-colour launches");
+}
+
 static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
-                     double *energies_per_step, float *device_ms, bool sync = true)
+                     double *energies_per_step, float *device_ms, bool sync = true, bool final_counts = false)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (timesteps && !betas && !s->has_betas) return fail(ISINGMC_ERR_INVALID, "betas is NULL");
@@ -1233,10 +1355,12 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
                           !resident_disabled();
     // per-step counters: 16 B per (step, replica) and counter slot, at most 32 MiB per chunk on each side of the bus
-    const size_t step_slots = (energies_per_step && lattice && !resident) ? MEASURE_SLOTS : 1;
+    const StripPlan strip = (lattice && !resident) ? strip_plan(s, timesteps) : StripPlan{};
+    s->meas_fresh = false;
+    const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use) ? MEASURE_SLOTS : 1;
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
     const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
-    if (resident || gen_resident) chunk = std::min<size_t>(chunk, 65536);
+    if (resident || gen_resident || strip.use) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
     long long *d_gen_mags = nullptr;
@@ -1256,13 +1380,13 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         TRY(scratch.alloc(&d_steps, chunk * R * 2 * step_slots));
         h_steps.resize(chunk * R * 2 * step_slots);
     }
-    if (resident && !s->has_betas) TRY(scratch.alloc(&d_thr_steps, beta_stride ? chunk : 1));
+    if ((resident || strip.use) && !s->has_betas) TRY(scratch.alloc(&d_thr_steps, beta_stride ? chunk : 1));
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
     // replica blocks on several streams.  Large launches (c2) keep the chip full on one stream.
     size_t want_lanes = 1;
-    if (lattice && !resident && !energies_per_step) {
+    if (lattice && !resident && !strip.use && !energies_per_step) {
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
@@ -1297,6 +1421,26 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             s->t += nk;
             if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
         }
+        if (strip.use) { // mid-size lattices: the whole chunk of timesteps in one persistent launch per block of replicas
+            if (!s->has_betas) {
+                h_thr.resize(beta_stride ? nk : 1);
+                for (size_t k = 0; k < h_thr.size(); k++) h_thr[k] = lattice_thresholds(betas[(k0 + k) * beta_stride], g->jabs);
+                HIP_TRY(hipMemcpyAsync(d_thr_steps, h_thr.data(), h_thr.size() * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
+            }
+            const bool last = k0 + nk == timesteps;
+            if (final_counts && last) { // the energies of the final configurations come with the last launch (tempering rounds)
+                if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+                s->meas_zero = false;
+            }
+            for (size_t r0 = 0; r0 < R && rc == ISINGMC_OK; r0 += strip.replicas_per_pass)
+                rc = launch_strip(s, strip, r0, std::min(strip.replicas_per_pass, R - r0), nk, d_thr_steps, uint32_t(beta_stride ? 1 : 0),
+                                  d_steps ? d_steps + 2 * r0 : nullptr, final_counts && last ? s->d_meas + 2 * r0 : nullptr);
+            if (rc != ISINGMC_OK) break;
+            s->strip_epoch += uint32_t(2 * nk);
+            s->t += nk;
+            if (final_counts && last) s->meas_fresh = true;
+            if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
+        }
         if (gen_resident) {
             const size_t nb = beta_stride ? nk : 1;
             if (!s->has_betas) HIP_TRY(hipMemcpyAsync(d_beta_steps, betas + k0 * beta_stride, nb * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1321,7 +1465,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                 HIP_TRY(hipStreamSynchronize(s->stream));
             }
         }
-        for (size_t k = k0; k < k0 + nk && !resident && !gen_resident; k++) {
+        for (size_t k = k0; k < k0 + nk && !resident && !gen_resident && !strip.use; k++) {
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
             if (lattice) {
                 const LatThr thr = lattice_thresholds(beta, g->jabs);
@@ -1367,7 +1511,10 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     }
     if (rc != ISINGMC_OK) return rc;
     HIP_TRY(hipGetLastError());
-    if (sync) HIP_TRY(hipStreamSynchronize(s->stream));
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (strip.use) TRY(strip_check(s));
+    }
     return ISINGMC_OK;
 }
 
@@ -1566,7 +1713,7 @@ extern "C" int isingmc_synchronize(isingmc_states *s)
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     TRY(use_device(s->g->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return ISINGMC_OK;
+    return strip_check(s);
 }
 
 extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
@@ -1630,7 +1777,8 @@ extern "C" int isingmc_pt_buffers(isingmc_states *s, void **d_local_out, void **
 extern "C" int isingmc_pt_time_steps(isingmc_states *s, size_t timesteps)
 {
     if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false);
+    // the strip kernel measures the final configurations itself: isingmc_pt_measure then needs no pass over the planes
+    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false, /*final_counts=*/true);
 }
 
 // enqueue: energies of the local slots -> the local send buffer (and straight into the gathered
@@ -1645,8 +1793,11 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
         // three launches per round: the conversion kernel leaves the counters zeroed for the next round and, on
         // a single rank, writes straight into the gathered array (no memset, no device-to-device copy)
-        if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
-        LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
+        if (!s->meas_fresh) {
+            if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+            LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
+        }
+        s->meas_fresh = false;
         hipLaunchKernelGGL(lat_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas,
                            uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
                            s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
@@ -1675,6 +1826,7 @@ extern "C" int isingmc_pt_state(isingmc_states *s, uint32_t *perm_out, uint64_t 
     if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
     TRY(use_device(s->g->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    TRY(strip_check(s));
     unsigned long long c[2];
     HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
     if (perm_out) HIP_TRY(hipMemcpy(perm_out, s->d_pt_perm, s->pt.n_rungs * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -416,10 +416,12 @@ def test_large_launch_takes_the_looping_kernel_bit_exact(capi, oracle, exact, gl
 
 # ---- round 2: the three lattice-kernel branches that had no oracle comparison ----------
 
-def test_per_step_energies_many_workgroups_per_replica(capi, oracle, exact):
+@pytest.mark.parametrize("strip", ["0", "1"])
+def test_per_step_energies_many_workgroups_per_replica(capi, oracle, exact, monkeypatch, strip):
     """lat_sweep_measure_kernel with 32 workgroups per replica (4096 x 512: 8192 quads per colour): the 16 counter
     slots per replica are each hit twice and summed on the host -- energies after every timestep
     (lattice.rs:445-455) and the final configuration against the oracle, +-J couplings."""
+    monkeypatch.setenv("ISINGMC_STRIP", strip)     # "0": the streaming kernels; "1": the persistent strip kernel (32 strips)
     W, H, T, beta = 4096, 512, 3, 0.7
     ea, eb, ej = exact.square_lattice_edges(W, H, 1.0, np.random.default_rng(12))
     g = capi.Graph(ea, eb, ej)
@@ -437,9 +439,10 @@ def test_per_step_energies_many_workgroups_per_replica(capi, oracle, exact):
         np.testing.assert_array_equal(packed[r], ref)
 
 
-def test_per_step_energies_2048_square_vs_separate_measurement(capi, oracle, exact):
+def test_per_step_energies_2048_square_vs_separate_measurement(capi, oracle, exact, monkeypatch):
     """BASELINE c4's geometry (2048^2: 64 workgroups per replica, every counter slot hit 4x): the fused per-step
     energies equal lat_measure_kernel's after single steps, and K1 (host recomputation from the returned spins)."""
+    monkeypatch.setenv("ISINGMC_STRIP", "0")       # this test is about lat_sweep_measure_kernel's counter slots
     L, T = 2048, 3
     ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
     g = capi.Graph(ea, eb, ej)
