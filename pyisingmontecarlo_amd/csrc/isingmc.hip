@@ -20,7 +20,7 @@
 #include "host_logic.hpp"
 #include "lattice_kernels.hpp"
 #include "packed_kernels.hpp"
-#include "strip_kernels.hpp"
+#include "strip_types.hpp"
 
 using namespace isingmc;
 
@@ -118,7 +118,8 @@ struct isingmc_states {
     size_t halo_cap = 0; // granules allocated
     uint32_t *d_strip_err = nullptr;
     uint32_t strip_epoch = 0;
-    bool meas_fresh = false; // d_meas holds the counts of the CURRENT configurations (fused into the last strip launch)
+    unsigned long long *d_strip_fin = nullptr; // [cap] final-measurement counters of the strip kernel (zero between launches)
+    bool meas_fresh = false; // the tempering send buffer holds the energies of the CURRENT configurations (written by the last strip launch)
     // on-stream parallel tempering (isingmc_pt_*)
     bool pt_attached = false;
     PtDev pt{};
@@ -138,6 +139,7 @@ struct isingmc_states {
         if (d_tab) (void)hipFree(d_tab);
         if (d_halo) (void)hipFree(d_halo);
         if (d_strip_err) (void)hipFree(d_strip_err);
+        if (d_strip_fin) (void)hipFree(d_strip_fin);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
                         (void *)d_pt_counters})
             if (p) (void)hipFree(p);
@@ -1225,6 +1227,7 @@ static bool resident_disabled()
 // ------------------------------------------------------------------------------------------------
 struct StripPlan {
     bool use = false;
+    int nw = 1; // waves per strip (workgroup)
     StripArgs a{};
     size_t replicas_per_pass = 0; // a pass = one launch over a block of replicas for all timesteps of the chunk
 };
@@ -1236,8 +1239,7 @@ static int env_int(const char *name, int dflt)
 }
 
 // Mid-size lattices only: a per-colour launch of the streaming kernel must be short enough for the ~5 us it loses
-// between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups per launch, default 2 x the resident
-// limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
+// between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups in all, default the resident limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
 // half-sweep must fit one workgroup (2 rows of <= 128 words).  ISINGMC_STRIP=0 disables, =1 forces (tests, A/B runs).
 static StripPlan strip_plan(const isingmc_states *s, size_t timesteps)
 {
@@ -1246,15 +1248,17 @@ static StripPlan strip_plan(const isingmc_states *s, size_t timesteps)
     const int mode = env_int("ISINGMC_STRIP", -1);
     if (mode == 0 || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
     const uint32_t qpr = g->geom.wpr / 4;
-    if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, 2 * wpr <= 256 polling lanes
-    const uint32_t S = 256 / qpr;
+    if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, at least two rows per wave
+    P.nw = env_int("ISINGMC_STRIP_NW", 4) == 1 ? 1 : 4; // measured on 1024^2 x 64: 9.6 us per timestep either way; with exchange rounds 11.5 (4) / 12.0 (1)
+    const uint32_t S = 64 * uint32_t(P.nw) / qpr;
     if (g->geom.H % S != 0 || g->geom.H / S < 2) return P;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
-    const size_t limit = size_t(STRIP_MAX_WG_PER_CU) * size_t(std::max(dev_cus, 1));
+    const size_t limit = size_t(STRIP_MAX_WAVES_PER_CU) * size_t(std::max(dev_cus, 1)) / size_t(P.nw); // workgroups resident at once
     const size_t n_strips = g->geom.H / S, total = s->R * n_strips;
     if (n_strips > limit) return P;
-    if (mode != 1 && total > size_t(env_int("ISINGMC_STRIP_MAX_WG", int(2 * limit)))) return P;
+    // one pass only by default: with twice the replicas (1024^2 x 128) the per-colour launches are long enough to win (16.7 vs 18.6 us)
+    if (mode != 1 && total > size_t(env_int("ISINGMC_STRIP_MAX_WG", int(limit)))) return P;
     const size_t passes = (total + limit - 1) / limit;
     P.replicas_per_pass = (s->R + passes - 1) / passes;
     while (P.replicas_per_pass * n_strips > limit) P.replicas_per_pass--;
@@ -1274,7 +1278,7 @@ static hipEvent_t g_strip_done[64] = {};
 
 // one pass: replicas [r0, r0 + n) for timesteps [s->t, s->t + nk).  steps_out / final_out: see lat_strip_kernel
 static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t n, size_t nk, const LatThr *d_thr_steps,
-                        uint32_t thr_stride, unsigned long long *steps_out, unsigned long long *final_out)
+                        uint32_t thr_stride, unsigned long long *steps_out, double *final_energies)
 {
     const isingmc_graph *g = s->g;
     const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
@@ -1291,6 +1295,14 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
         TRY(dev_alloc(&s->d_strip_err, 4));
         HIP_TRY(hipMemsetAsync(s->d_strip_err, 0, 4 * sizeof(uint32_t), s->stream));
     }
+    StripFinal fin{nullptr, nullptr, 0.0, 0};
+    if (final_energies) {
+        if (!s->d_strip_fin) {
+            TRY(dev_alloc(&s->d_strip_fin, s->cap));
+            HIP_TRY(hipMemsetAsync(s->d_strip_fin, 0, s->cap * sizeof(unsigned long long), s->stream));
+        }
+        fin = StripFinal{s->d_strip_fin + r0, final_energies + r0, g->jabs, 2ll * (long long)g->nvars};
+    }
     if (uint64_t(s->strip_epoch) + 2 * nk + 2 >= 0xFFFFFFF0ull) { // tags are unique per states object: restart them
         HIP_TRY(hipMemsetAsync(s->d_halo, 0, s->halo_cap * sizeof(unsigned long long), s->stream));
         s->strip_epoch = 0;
@@ -1304,15 +1316,10 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
         hipEvent_t &ev = g_strip_done[g->device & 63];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(s->stream, ev, 0));
-        const auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(unsigned(n * a.n_strips)), dim3(256), lds, s->stream, s->d_state + r0 * g->state_words,
-                               g->geom, a, s->t, uint32_t(nk), s->d_keys + r0, d_thr_steps, thr_stride,
-                               s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg, g->jneg_uniform,
-                               s->d_halo + r0 * size_t(a.n_strips) * 4 * g->geom.wpr, steps_out, final_out, uint32_t(s->R),
-                               s->d_strip_err);
-        };
-        if (g->uniform_sign) launch(lat_strip_kernel<false>); else launch(lat_strip_kernel<true>);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(strip_launch(!g->uniform_sign, P.nw, unsigned(n * a.n_strips), lds, s->stream, s->d_state + r0 * g->state_words, g->geom, a, s->t,
+                             uint32_t(nk), s->d_keys + r0, d_thr_steps, thr_stride, s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg,
+                             g->jneg_uniform, s->d_halo + r0 * size_t(a.n_strips) * 4 * g->geom.wpr, steps_out, fin, uint32_t(s->R),
+                             s->d_strip_err));
         HIP_TRY(hipEventRecord(ev, s->stream));
     }
     return ISINGMC_OK;
@@ -1326,13 +1333,14 @@ static int strip_check(isingmc_states *s)
     HIP_TRY(hipMemcpy(&h, s->d_strip_err, sizeof h, hipMemcpyDeviceToHost));
     if (h == 0) return ISINGMC_OK;
     (void)hipMemset(s->d_strip_err, 0, sizeof h);
+    if (s->d_strip_fin) (void)hipMemset(s->d_strip_fin, 0, s->cap * sizeof(unsigned long long));
     return fail(ISINGMC_ERR_HIP, "the persistent strip kernel timed out waiting for a neighbour strip (its workgroups were not all "
                                  "resident: is another process using this GPU?); the configurations of this object are invalid. "
                                  "ISINGMC_STRIP=0 selects the per-colour launches");
 }
 
 static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
-                     double *energies_per_step, float *device_ms, bool sync = true, bool final_counts = false)
+                     double *energies_per_step, float *device_ms, bool sync = true, double *final_energies = nullptr)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (timesteps && !betas && !s->has_betas) return fail(ISINGMC_ERR_INVALID, "betas is NULL");
@@ -1427,18 +1435,15 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                 for (size_t k = 0; k < h_thr.size(); k++) h_thr[k] = lattice_thresholds(betas[(k0 + k) * beta_stride], g->jabs);
                 HIP_TRY(hipMemcpyAsync(d_thr_steps, h_thr.data(), h_thr.size() * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
             }
+            // final_energies (device, [R]): the energies of the final configurations come with the last launch (tempering rounds)
             const bool last = k0 + nk == timesteps;
-            if (final_counts && last) { // the energies of the final configurations come with the last launch (tempering rounds)
-                if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
-                s->meas_zero = false;
-            }
             for (size_t r0 = 0; r0 < R && rc == ISINGMC_OK; r0 += strip.replicas_per_pass)
                 rc = launch_strip(s, strip, r0, std::min(strip.replicas_per_pass, R - r0), nk, d_thr_steps, uint32_t(beta_stride ? 1 : 0),
-                                  d_steps ? d_steps + 2 * r0 : nullptr, final_counts && last ? s->d_meas + 2 * r0 : nullptr);
+                                  d_steps ? d_steps + 2 * r0 : nullptr, last ? final_energies : nullptr);
             if (rc != ISINGMC_OK) break;
             s->strip_epoch += uint32_t(2 * nk);
             s->t += nk;
-            if (final_counts && last) s->meas_fresh = true;
+            if (final_energies && last) s->meas_fresh = true;
             if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
         }
         if (gen_resident) {
@@ -1778,7 +1783,8 @@ extern "C" int isingmc_pt_time_steps(isingmc_states *s, size_t timesteps)
 {
     if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
     // the strip kernel measures the final configurations itself: isingmc_pt_measure then needs no pass over the planes
-    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false, /*final_counts=*/true);
+    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false,
+                     /*final_energies=*/s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
 }
 
 // enqueue: energies of the local slots -> the local send buffer (and straight into the gathered
@@ -1793,11 +1799,12 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
     if (g->kind == ISINGMC_KIND_LATTICE2D) {
         // three launches per round: the conversion kernel leaves the counters zeroed for the next round and, on
         // a single rank, writes straight into the gathered array (no memset, no device-to-device copy)
-        if (!s->meas_fresh) {
-            if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
-            LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
+        if (s->meas_fresh) { // the last strip launch of isingmc_pt_time_steps has already written these energies
+            s->meas_fresh = false;
+            return ISINGMC_OK;
         }
-        s->meas_fresh = false;
+        if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
         hipLaunchKernelGGL(lat_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas,
                            uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
                            s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);

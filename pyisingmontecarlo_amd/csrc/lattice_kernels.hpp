@@ -299,6 +299,38 @@ __device__ __forceinline__ void quad_classes(const uint32_t own[4], const QuadNb
 // NQ > 1 decides several quads together (the wave-uniform work is then issued once); measured, a two-quad
 // kernel built on it ran exactly as fast as the one-quad kernel (the kernel is bound by VALU cycles, which
 // are the same per quad, and the scalar unit runs beside it), so only NQ = 1 is instantiated.
+// one plane of the comparison for the four words rr[] of a quad (plane p = Philox call p): what quad_planes does per
+// plane, for callers that hold the random words already (kept apart from quad_planes: routing the streaming kernels
+// through it cost lat_sweep_loop_kernel two registers, 66 instead of 64 = a wave per SIMD)
+__device__ __forceinline__ void plane_step(QuadState &st, const uint32_t rr[4], const int p, const ThrBits &tb)
+{
+    // threshold bit of this plane for class 3 / class 4: wave-uniform, so the per-spin threshold word is
+    // one of {0, eq3, eq4, eq3|eq4} -- scalar branches pick the register
+    const auto step = [&](int q, uint32_t tbw) {
+        st.lt[q] = __builtin_amdgcn_bitop3_b32(rr[q], tbw, st.lt[q], 0x8E);   // (~r & tb) | (~(r ^ tb) & lt)
+        st.und[q] = __builtin_amdgcn_bitop3_b32(st.und[q], rr[q], tbw, 0x90); // eq & ~(r ^ tb)
+    };
+    // one scalar selector per plane (the scalar unit runs beside the vector ALU; as two nested bool tests the
+    // compiler parked the second bool in a VGPR: a v_cndmask and a v_cmp per plane)
+    const uint32_t sel = __builtin_amdgcn_readfirstlane(((tb.hi3 >> (N_PLANES - 1 - p)) & 1u) | (((tb.hi4 >> (N_PLANES - 1 - p)) & 1u) << 1));
+    if (sel == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) step(q, st.eq3[q] | st.eq4[q]);
+    } else if (sel == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) step(q, st.eq3[q]);
+    } else if (sel == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) step(q, st.eq4[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            st.lt[q] &= ~rr[q];
+            st.und[q] &= ~rr[q];
+        }
+    }
+}
+
 template <int NQ>
 __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t (&Q)[NQ], const uint32_t colour, const uint64_t t,
                                             const uint2 key, const PhiloxVKeys &vk, const ThrBits &tb)
@@ -348,9 +380,31 @@ __device__ __forceinline__ void quad_planes(QuadState (&st)[NQ], const uint32_t 
     }
 }
 
+// The random words of a quad's half-sweep do not depend on the spins: a kernel that has to wait for its neighbours
+// (strip_kernels.hpp) draws them BEFORE the wait.  rr[p] = plane p, tie = the first residual call.
+// (Two calls written side by side, their rounds interleaved by volatile asm, ran 1-2 % SLOWER at 4 waves per SIMD:
+// a lone wave is bound by its ~4-cycle issue interval, not by the multiply -> xor dependency chain.)
+struct QuadRandom {
+    uint32_t rr[N_PLANES][4];
+    uint4 tie;
+};
+
+__device__ __forceinline__ void quad_random(QuadRandom &R, const uint32_t Q, const uint32_t colour, const uint64_t t, const uint2 key,
+                                            const PhiloxVKeys &vk)
+{
+    const uint32_t c0 = uint32_t(t);
+#pragma unroll
+    for (int p = 0; p < N_PLANES; p++) {
+        const uint4 rnd = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, p)), key, vk);
+        R.rr[p][0] = rnd.x; R.rr[p][1] = rnd.y; R.rr[p][2] = rnd.z; R.rr[p][3] = rnd.w;
+    }
+    R.tie = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+}
+
 // residual stage: spins whose prefix equals the threshold's top bits (ties) draw 32 more bits; acc = flips
 __device__ __forceinline__ void quad_ties(const QuadState &st, const uint32_t Q, const uint32_t colour, const uint64_t t,
-                                          const uint2 key, const PhiloxVKeys &vk, const ThrBits &tb, uint32_t acc[4])
+                                          const uint2 key, const PhiloxVKeys &vk, const ThrBits &tb, uint32_t acc[4],
+                                          const uint4 *first_call = nullptr)
 {
     const uint32_t c0 = uint32_t(t), c1 = Q;
 #pragma unroll
@@ -362,7 +416,7 @@ __device__ __forceinline__ void quad_ties(const QuadState &st, const uint32_t Q,
 #endif
         // the first residual call is hoisted: inside the divergent per-word loops below it would be
         // issued once per loop (up to 4x per wave) instead of once
-        const uint4 rnd = philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+        const uint4 rnd = first_call ? *first_call : philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
         const uint32_t n_ties = __popc(st.und[0]) + __popc(st.und[1]) + __popc(st.und[2]) + __popc(st.und[3]);
         if (n_ties <= 4) {
             // all but ~0.1 % of the quads: the ties consume the four words of this one call in order.  The words
@@ -418,6 +472,21 @@ __device__ __forceinline__ void quad_flips(const uint32_t own[4], const QuadNbr 
     quad_classes<PMJ>(own, n, widx, g, tb, js, jneg_uniform, st[0]);
     quad_planes<1>(st, Qs, colour, t, key, vk, tb);
     quad_ties(st[0], Q, colour, t, key, vk, tb, acc);
+}
+
+// the same decisions from random words drawn earlier (quad_random)
+template <bool PMJ>
+__device__ __forceinline__ void quad_flips_pre(const uint32_t own[4], const QuadNbr &n, const uint32_t widx[4], const LatGeom &g,
+                                               const uint32_t colour, const uint64_t t, const uint2 key, const PhiloxVKeys &vk,
+                                               const LatThr thr, const QuadSigns &js, const uint32_t jneg_uniform, const uint32_t Q,
+                                               const QuadRandom &R, uint32_t acc[4])
+{
+    const ThrBits tb = thr_bits(thr);
+    QuadState st;
+    quad_classes<PMJ>(own, n, widx, g, tb, js, jneg_uniform, st);
+#pragma unroll
+    for (int p = N_PLANES - 1; p >= 0; p--) plane_step(st, R.rr[p], p, tb);
+    quad_ties(st, Q, colour, t, key, vk, tb, acc, &R.tie);
 }
 
 // One Metropolis update of the 128 spins of a quad (thread index gid -> quad via thread_to_quad) of the
@@ -640,7 +709,7 @@ __global__ __launch_bounds__(256) void lat_sweep_loop_kernel(
 }
 
 // Random initial configuration: word w of plane c = Philox(key, (0, w>>2, c<<8, "LATI"))[w&3].
-__global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void lat_init_kernel(uint32_t *__restrict__ state, const LatGeom g,
                                                        const uint2 *__restrict__ keys,
                                                        const uint32_t first_replica)
 {
@@ -772,7 +841,7 @@ __global__ __launch_bounds__(1024) void lat_resident_kernel(
 }
 
 // lattice energies from the satisfied-bond counters: E = |J| (n_bonds - 2 sat)  (exact in f64)
-__global__ void lat_energy_from_counts_kernel(unsigned long long *__restrict__ meas, const uint32_t n,
+__attribute__((unused)) static __global__ void lat_energy_from_counts_kernel(unsigned long long *__restrict__ meas, const uint32_t n,
                                               const double jabs, const long long n_bonds, double *__restrict__ out)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;

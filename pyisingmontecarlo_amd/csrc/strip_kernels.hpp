@@ -2,42 +2,32 @@
 // synchronisation (replaces the two dependent launches per timestep that bound launches of a few waves per SIMD:
 // the 1024^2 x 64-rung tempering ladder of BASELINE config c3 spent 11 of its 18 us per timestep between kernels).
 //
-// A replica is cut into horizontal strips of S rows, S x (quads per row) = 256: one workgroup owns one strip for
-// the whole launch and keeps both colour planes of it in LDS (8 KB + two halo rows).  A half-sweep of colour c
-// reads the other colour's rows y-1 / y+1, so a strip needs exactly one row of each vertical neighbour strip per
-// half-sweep.  Those two rows travel through global memory as 8-byte {tag, word} granules, each ONE relaxed
-// agent-scope atomic store / load (cdna_hip_programming.md Guideline 16, form R2: the datum is its own flag,
-// no fence, no separate flag, correct for any workgroup -> CU / XCD placement): after its half-sweep j a
+// A replica is cut into horizontal strips of S rows, S x (quads per row) = 64 NW: one workgroup of NW waves owns one
+// strip for the whole launch and keeps both colour planes of it in LDS (2 KB per wave + two halo rows).  A
+// half-sweep of colour c reads the other colour's rows y-1 / y+1, so a strip needs exactly one row of each vertical
+// neighbour strip per half-sweep.  Those two rows travel through global memory as 8-byte {tag, word} granules, each
+// ONE relaxed agent-scope atomic store / load (cdna_hip_programming.md Guideline 16, form R2: the datum is its own
+// flag, no fence, no separate flag, correct for any workgroup -> CU / XCD placement): after its half-sweep j a
 // workgroup stores its top and bottom row with tag = epoch + j + 1; before half-sweep j + 1 its neighbours poll
 // those granules until the tag matches.  Nothing else is shared during the launch: the strips' spins are loaded
 // from the state array at the start (the first half-sweep's halo rows too: they were written before the launch)
 // and stored back at the end.  A workgroup cannot overwrite a granule its neighbour still needs: it can only be
 // one half-sweep ahead of it, and the colours alternate.
 //
+// NW = 1: a strip is ONE wavefront -- no workgroup barrier anywhere (a wave's LDS accesses execute in order), every
+// wave waits only for its own two neighbours, and the four waves of a SIMD drift apart, so one wave's hand-off
+// latency is covered by the others' arithmetic.  NW = 4: 256-thread workgroups, one barrier per half-sweep.
+//
 // Every workgroup of the launch must be resident at once (a strip spins on its neighbours): the host launches at
-// most STRIP_MAX_WG_PER_CU x #CUs workgroups and serialises strip launches of one process on a device; every spin
+// most STRIP_MAX_WAVES_PER_CU x #CUs waves and serialises strip launches of one process on a device; every spin
 // is bounded by the constant-rate counter (s_memrealtime) -- on a timeout the workgroup raises *err and leaves, and
 // its neighbours follow within one poll.  Same Philox counters (global quad index, timestep, colour) as the
 // per-colour launches => bit-identical configurations.
 #pragma once
 #include "lattice_kernels.hpp"
+#include "strip_types.hpp"
 
 namespace isingmc {
-
-constexpr uint32_t STRIP_MAX_WG_PER_CU = 4;               // residency by grid size alone (Guideline 16: <= 4 blocks of 256)
-constexpr unsigned long long STRIP_TIMEOUT_TICKS = 200000000ull; // 2 s of the 100 MHz counter
-constexpr uint32_t STRIP_ERR_TIMEOUT = 1u;
-
-typedef unsigned long long __attribute__((address_space(1))) * strip_gu64;
-typedef uint32_t __attribute__((address_space(1))) * strip_gu32;
-
-struct StripArgs {
-    uint32_t S;         // rows per strip; S * (wpr / 4) == 256
-    uint32_t n_strips;  // H / S >= 2
-    uint32_t qpr_log2;  // log2(wpr / 4)
-    uint32_t epoch;     // tags of this launch are epoch + 1 ... epoch + 2 * timesteps (never 0, never reused)
-    uint32_t xcd_remap; // n_replicas % 8 == 0: the strips of a replica share blockIdx % 8 (one XCD; speed only)
-};
 
 // granules of one replica: [strip][plane][side: 0 = its top row, 1 = its bottom row][wpr]
 __device__ __forceinline__ size_t strip_granule(const LatGeom &g, uint32_t strip, uint32_t plane, uint32_t side)
@@ -47,15 +37,12 @@ __device__ __forceinline__ size_t strip_granule(const LatGeom &g, uint32_t strip
 
 template <bool PMJ>
 __device__ __forceinline__ void strip_update_quad(uint32_t *lds, const uint32_t PL, const LatGeom &g, const uint32_t colour,
-                                                  const uint32_t yl, const uint32_t col, const uint32_t y_global, const uint64_t t,
+                                                  const uint32_t yl, const uint32_t col, const uint32_t Q, const bool odd, const uint64_t t,
                                                   const uint2 key, const PhiloxVKeys &vk, const LatThr thr,
-                                                  const uint32_t *__restrict__ jn, const uint32_t jneg_uniform, uint32_t new_words[4],
-                                                  const bool measure, uint32_t &sat, uint32_t &up)
+                                                  const uint32_t *__restrict__ jn, const uint32_t jneg_uniform, const QuadRandom &R,
+                                                  uint32_t new_words[4], const bool measure, uint32_t &sat, uint32_t &up)
 {
     const uint32_t wpr = g.wpr, xw = 4 * col;
-    const uint32_t Q = y_global * (wpr >> 2) + col; // the GLOBAL quad index: the Philox counter of the per-colour launches
-    // row parity is wave-uniform under the thread -> row map of the kernel: scalar branch for the side neighbour
-    const bool odd = __builtin_amdgcn_readfirstlane((y_global + colour) & 1u) != 0;
     uint32_t *ownp = lds + colour * PL;
     const uint32_t *othp = lds + (1 - colour) * PL;
     const uint32_t w0 = yl * wpr + xw;
@@ -74,29 +61,35 @@ __device__ __forceinline__ void strip_update_quad(uint32_t *lds, const uint32_t 
     n.dn[0] = d4.x; n.dn[1] = d4.y; n.dn[2] = d4.z; n.dn[3] = d4.w;
     side_words(n, odd);
     const uint32_t widx[4] = {0, 0, 0, 0}; // only the PMJ = false bond masks take it, and ignore it
+#ifdef ISINGMC_STRIP_NO_PRECOMPUTE // A/B build: the random words drawn after the wait, as in the streaming kernels
+    (void)R;
     quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
+#else
+    quad_flips_pre<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, R, acc);
+#endif
 #pragma unroll
     for (int q = 0; q < 4; q++) new_words[q] = own[q] ^ acc[q];
     *reinterpret_cast<uint4 *>(ownp + w0) = make_uint4(new_words[0], new_words[1], new_words[2], new_words[3]);
     if (measure) quad_measure<PMJ>(new_words, n, js, jneg_uniform, sat, up); // wave-uniform
 }
 
-// grid: n_replicas * n_strips workgroups of 256 threads; dynamic LDS: 2 planes x (S + 2) rows x wpr words
+// grid: n_replicas * n_strips workgroups of 64 NW threads; dynamic LDS: 2 planes x (S + 2) rows x wpr words + 16 words
 // thr_steps / thr_stride / thr_replica: as lat_resident_kernel.  steps_out (optional): satisfied bonds / up spins
 // after every timestep, [step][replica][2], zeroed by the host (the strips of a replica add into it).
-// final_out (optional): the same after the LAST timestep, [replica][2], zeroed by the host.
-template <bool PMJ>
-__global__ __launch_bounds__(256, 4) void lat_strip_kernel(
+// fin (optional): energies of the final configurations, see StripFinal.
+template <bool PMJ, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const StripArgs a, const uint64_t t0, const uint32_t timesteps,
     const uint2 *__restrict__ keys, const LatThr *__restrict__ thr_steps, const uint32_t thr_stride,
     const LatThr *__restrict__ thr_replica, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
-    unsigned long long *__restrict__ halo, unsigned long long *__restrict__ steps_out, unsigned long long *__restrict__ final_out,
+    unsigned long long *__restrict__ halo, unsigned long long *__restrict__ steps_out, const StripFinal fin,
     const uint32_t n_replicas, uint32_t *__restrict__ err)
 {
+    constexpr uint32_t NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[]; // [plane][S + 2 rows][wpr] + 16 words of scratch
     const uint32_t tid = threadIdx.x, wpr = g.wpr, S = a.S;
     const uint32_t PL = (S + 2) * wpr;
-    uint32_t *red = lds + 2 * PL; // [0..7]: per-wave partial sums, [8]: bail flag
+    uint32_t *red = lds + 2 * PL; // NW > 1: [0..7] per-wave partial sums, [8] bail flag
     uint32_t r, strip;
     if (a.xcd_remap) { // blocks b and b + 8 share an XCD: keep a replica's strips (which exchange rows) on one L2
         const uint32_t x = blockIdx.x & 7u, m = blockIdx.x >> 3;
@@ -111,25 +104,26 @@ __global__ __launch_bounds__(256, 4) void lat_strip_kernel(
     uint32_t *mine = state + size_t(r) * 2 * g.wpp;
     unsigned long long *rep_halo = halo + size_t(r) * a.n_strips * 4 * wpr;
 
-    // ---- load: own rows (S * wpr = 1024 words per plane: one 16-byte load per thread and plane) + the two halo rows
+    // ---- load: own rows (S * wpr = 4 NT words per plane: one 16-byte load per thread and plane) + the two halo rows
     //      of both planes, all written before this launch
 #pragma unroll
     for (uint32_t p = 0; p < 2; p++)
         reinterpret_cast<uint4 *>(lds + p * PL + wpr)[tid] = reinterpret_cast<const uint4 *>(mine + size_t(p) * g.wpp + size_t(y0) * wpr)[tid];
     const uint32_t y_up = (y0 == 0 ? g.H : y0) - 1, y_dn = (y0 + S == g.H) ? 0 : y0 + S;
-    for (uint32_t i = tid; i < 4 * wpr; i += 256) {
+    for (uint32_t i = tid; i < 4 * wpr; i += NT) {
         const uint32_t p = i / (2 * wpr), side = (i / wpr) & 1u, w = i % wpr;
         lds[p * PL + (side ? (S + 1) * wpr : 0) + w] = mine[size_t(p) * g.wpp + size_t(side ? y_dn : y_up) * wpr + w];
     }
-    if (tid == 0) red[8] = 0;
+    if (NW > 1 && tid == 0) red[8] = 0;
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
 
-    // thread -> quad of the strip: a pair of waves shares 2 * rpw consecutive rows, wave 0 the even ones, wave 1 the
-    // odd ones (rpw = 64 / quads per row), so the row parity is uniform per wavefront (as thread_to_quad<true>)
+    // thread -> quad of the strip.  NW = 4: a pair of waves shares 2 * rpw consecutive rows, wave 0 the even ones, wave 1
+    // the odd ones (rpw = 64 / quads per row), so the row parity is uniform per wavefront (as thread_to_quad<true>).
+    // NW = 1: the wave's 64 quads in row-major order, parity per lane.
     const uint32_t ql = a.qpr_log2, wave = tid >> 6, lane = tid & 63u;
     uint32_t yrel, col;
-    if (ql >= 6) {
+    if (NW == 1 || ql >= 6) {
         yrel = tid >> ql;
         col = tid & ((1u << ql) - 1);
     } else {
@@ -138,42 +132,63 @@ __global__ __launch_bounds__(256, 4) void lat_strip_kernel(
     }
     const uint32_t yl = yrel + 1, y_global = y0 + yrel;
     const bool top_row = yrel == 0, bottom_row = yrel + 1 == S;
+    const uint32_t Q = y_global * (wpr >> 2) + col; // the GLOBAL quad index: the Philox counter of the per-colour launches
+    // The random words of a half-sweep do not depend on the spins: they are drawn BEFORE the wait for the neighbour
+    // strips' rows (7 + 1 Philox calls = two thirds of a half-sweep's work), so that the hand-off latency of the
+    // granules (~1-2 us) is covered by work instead of adding to every half-sweep.
+    QuadRandom R;
+#ifndef ISINGMC_STRIP_NO_PRECOMPUTE
+    quad_random(R, Q, 0, t0, key, vk);
+#endif
 
     for (uint32_t k = 0; k < timesteps; k++) {
         const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
         uint32_t sat = 0, up = 0;
-        const bool measure = (steps_out != nullptr) || (final_out != nullptr && k + 1 == timesteps);
+        const bool last_step = k + 1 == timesteps;
+        const bool measure = (steps_out != nullptr) || (fin.counts != nullptr && last_step);
 #pragma unroll 1
         for (uint32_t colour = 0; colour < 2; colour++) {
             const uint32_t j = 2 * k + colour; // half-sweep index of this launch
             // ---- halo rows of the OTHER colour as of half-sweep j - 1 (tag epoch + j), from the neighbour strips
-            if (j > 0 && tid < 2 * wpr) {
-                const uint32_t side = tid / wpr, w = tid - side * wpr; // 0: my top halo = up_strip's bottom row; 1: my bottom halo
-                const strip_gu64 src = (strip_gu64)(rep_halo + strip_granule(g, side ? dn_strip : up_strip, 1 - colour, side ? 0 : 1) + w);
-                const uint32_t want = a.epoch + j;
-                const unsigned long long start = __builtin_amdgcn_s_memrealtime();
-                uint32_t spins = 0;
-                for (;;) {
-                    const unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (uint32_t(v >> 32) == want) {
-                        lds[(1 - colour) * PL + (side ? (S + 1) * wpr : 0) + w] = uint32_t(v);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 63u) == 0 &&
-                        (__builtin_amdgcn_s_memrealtime() - start > STRIP_TIMEOUT_TICKS ||
-                         __hip_atomic_load((strip_gu32)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        atomicOr(err, STRIP_ERR_TIMEOUT); // the grid was not resident at once (or a neighbour gave up): leave
-                        red[8] = 1;
-                        break;
+            bool bail = false;
+#ifndef ISINGMC_STRIP_DEBUG_NOPOLL // (timing-only build, wrong results: what the waits cost)
+            if (j > 0) {
+                for (uint32_t i = tid; i < 2 * wpr; i += NT) {
+                    const uint32_t side = i / wpr, w = i - side * wpr; // 0: my top halo = up_strip's bottom row; 1: my bottom halo
+                    const strip_gu64 src = (strip_gu64)(rep_halo + strip_granule(g, side ? dn_strip : up_strip, 1 - colour, side ? 0 : 1) + w);
+                    const uint32_t want = a.epoch + j;
+                    const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+                    uint32_t spins = 0;
+                    for (;;) {
+                        const unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (uint32_t(v >> 32) == want) {
+                            lds[(1 - colour) * PL + (side ? (S + 1) * wpr : 0) + w] = uint32_t(v);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 63u) == 0 &&
+                            (__builtin_amdgcn_s_memrealtime() - start > STRIP_TIMEOUT_TICKS ||
+                             __hip_atomic_load((strip_gu32)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            atomicOr(err, STRIP_ERR_TIMEOUT); // the grid was not resident at once (or a neighbour gave up): leave
+                            bail = true;
+                            break;
+                        }
                     }
                 }
             }
-            __syncthreads(); // halo rows in place; everybody has finished the previous half-sweep's LDS stores
-            if (red[8]) return;
+#endif
+            if constexpr (NW > 1) {
+                if (bail) red[8] = 1;
+                __syncthreads(); // halo rows in place; everybody has finished the previous half-sweep's LDS stores
+                if (red[8]) return;
+            } else {
+                if (__any(bail)) return; // a wave's LDS accesses execute in order: no barrier
+            }
+            bool odd = (y_global + colour) & 1u;
+            if constexpr (NW > 1) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd)) != 0; // wave-uniform: scalar branch
             uint32_t nw[4];
-            strip_update_quad<PMJ>(lds, PL, g, colour, yl, col, y_global, t0 + k, key, vk, thr,
-                                   PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, nw, measure && colour == 1, sat, up);
+            strip_update_quad<PMJ>(lds, PL, g, colour, yl, col, Q, odd, t0 + k, key, vk, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr,
+                                   jneg_uniform, R, nw, measure && colour == 1, sat, up);
             // ---- publish my boundary rows of this colour (not after the last half-sweep: nobody waits for it)
             if ((top_row || bottom_row) && j + 1 < 2 * timesteps) {
                 const unsigned long long tag = (unsigned long long)(a.epoch + j + 1) << 32;
@@ -188,6 +203,9 @@ __global__ __launch_bounds__(256, 4) void lat_strip_kernel(
                     for (int q = 0; q < 4; q++) __hip_atomic_store(dst + q, tag | nw[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+#ifndef ISINGMC_STRIP_NO_PRECOMPUTE
+            if (j + 1 < 2 * timesteps) quad_random(R, Q, 1 - colour, t0 + k + colour, key, vk); // the next half-sweep's words
+#endif
         }
         if (measure) { // get_energy after this timestep (lattice.rs:454): the strips of a replica add up
 #pragma unroll
@@ -195,24 +213,33 @@ __global__ __launch_bounds__(256, 4) void lat_strip_kernel(
                 sat += __shfl_xor(sat, off);
                 up += __shfl_xor(up, off);
             }
-            __syncthreads(); // red[] of the previous timestep has been read
-            if (lane == 0) { red[wave] = sat; red[4 + wave] = up; }
-            __syncthreads();
+            unsigned long long s4 = sat, u4 = up;
+            if constexpr (NW > 1) {
+                __syncthreads(); // red[] of the previous timestep has been read
+                if (lane == 0) { red[wave] = sat; red[4 + wave] = up; }
+                __syncthreads();
+                s4 = (unsigned long long)red[0] + red[1] + red[2] + red[3];
+                u4 = (unsigned long long)red[4] + red[5] + red[6] + red[7];
+            }
             if (tid == 0) {
-                const unsigned long long s4 = (unsigned long long)red[0] + red[1] + red[2] + red[3];
-                const unsigned long long u4 = (unsigned long long)red[4] + red[5] + red[6] + red[7];
                 if (steps_out) {
                     atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2, s4);
                     atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2 + 1, u4);
                 }
-                if (final_out && k + 1 == timesteps) {
-                    atomicAdd(final_out + size_t(r) * 2, s4);
-                    atomicAdd(final_out + size_t(r) * 2 + 1, u4);
+                if (fin.counts && last_step) {
+                    // ONE atomic carries the count and the arrival: whoever sees n_strips - 1 earlier arrivals holds the total
+                    const unsigned long long mine_add = s4 | (1ull << STRIP_ARRIVAL_SHIFT);
+                    const unsigned long long old = atomicAdd(fin.counts + r, mine_add);
+                    if ((old >> STRIP_ARRIVAL_SHIFT) + 1 == a.n_strips) {
+                        const long long total = (long long)((old + mine_add) & ((1ull << STRIP_ARRIVAL_SHIFT) - 1));
+                        fin.energy_out[r] = fin.jabs * double(fin.n_bonds - 2 * total);
+                        __hip_atomic_store((strip_gu64)(fin.counts + r), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
     }
-    __syncthreads();
+    if constexpr (NW > 1) __syncthreads();
 #pragma unroll
     for (uint32_t p = 0; p < 2; p++)
         reinterpret_cast<uint4 *>(mine + size_t(p) * g.wpp + size_t(y0) * wpr)[tid] = reinterpret_cast<const uint4 *>(lds + p * PL + wpr)[tid];

@@ -17,8 +17,10 @@ def _oracle_lat(oracle, W, H, ej, glass):
 
 @pytest.mark.parametrize("W,H", [(1024, 128), (512, 1024), (2048, 64), (8192, 32), (256, 512), (4096, 64)])
 @pytest.mark.parametrize("glass", [False, True])
-def test_strip_kernel_bit_exact(capi, oracle, exact, monkeypatch, W, H, glass):
+@pytest.mark.parametrize("nw", ["1", "4"])
+def test_strip_kernel_bit_exact(capi, oracle, exact, monkeypatch, W, H, glass, nw):
     monkeypatch.setenv("ISINGMC_STRIP", "1")
+    monkeypatch.setenv("ISINGMC_STRIP_NW", nw)                     # strip = one wavefront (no barrier) / a 256-thread workgroup
     monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", "1")           # the small cases would otherwise stay in one workgroup
     ea, eb, ej = exact.square_lattice_edges(W, H, -1.0, np.random.default_rng(W + H) if glass else None)
     g = capi.Graph(ea, eb, ej)
@@ -73,7 +75,7 @@ def test_strip_kernel_equals_streaming_path_c3_geometry(capi, exact, monkeypatch
 def test_strip_kernel_in_several_passes(capi, oracle, exact, monkeypatch):
     """More workgroups than may be resident at once (4 per CU): the replicas go through in blocks, one launch each."""
     monkeypatch.setenv("ISINGMC_STRIP", "1")
-    W, H, R, T = 1024, 128, 700, 3                                 # 2 strips x 700 replicas = 1400 workgroups > 1024
+    W, H, R, T = 1024, 128, 700, 3                                 # 8 one-wave strips x 700 replicas = 5600 waves > 4096
     ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
     g = capi.Graph(ea, eb, ej)
     seeds = capi.make_seeds(8, R)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""c3 (1024^2, 64 rungs, exchange round every 10 sweeps) with the persistent strip kernel vs the per-colour launches,
-same box, interleaved.  python tools/c3_ab.py [steps]"""
+"""c3 (1024^2, 64 rungs, exchange round every 10 sweeps): same box, interleaved A/B.
+  python tools/c3_ab.py [steps] [lib.so ...]     default: the shipped library with ISINGMC_STRIP=1 and =0"""
 import json
 import os
 import subprocess
@@ -8,11 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 steps = sys.argv[1] if len(sys.argv) > 1 else "400"
+libs = sys.argv[2:]
+arms = [({"ISINGMC_LIB_PATH": os.path.abspath(l)}, l) for l in libs] or [({"ISINGMC_STRIP": "1"}, "strip"), ({"ISINGMC_STRIP": "0"}, "streaming")]
 for rep in range(2):
-    for mode in ("1", "0"):
-        env = dict(os.environ, ISINGMC_STRIP=mode)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c3", "--steps", steps], env=env,
-                             capture_output=True, text=True)
+    for env_add, label in arms:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c3", "--steps", steps],
+                             env=dict(os.environ, **env_add), capture_output=True, text=True)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         rec = json.loads(line[0]) if line else {"error": out.stderr[-400:]}
-        print(f"ISINGMC_STRIP={mode}", json.dumps(rec), flush=True)
+        print(label, json.dumps(rec), flush=True)
