@@ -275,7 +275,10 @@ static const uint64_t *spread_lut()
     return lut;
 }
 
-void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins)
+// STREAM: non-temporal 16-byte stores (the bool arrays are written once and read by the caller much later: without
+// the read-for-ownership of ordinary stores the expansion runs 2-2.7x faster, 5.5 -> 11-14 GB/s on 8 threads)
+template <bool STREAM>
+static void unpack_lattice_impl(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins)
 {
     const uint64_t *lut = spread_lut();
     const uint32_t wpr = W / 64;
@@ -290,10 +293,18 @@ void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spin
             for (int k = 0; k < 4; k++) { // 8 + 8 bits -> 16 interleaved bytes
                 const __m128i a = _mm_cvtsi64_si128((long long)lut[(we >> (8 * k)) & 0xFF]);
                 const __m128i b = _mm_cvtsi64_si128((long long)lut[(wo >> (8 * k)) & 0xFF]);
-                _mm_storeu_si128(reinterpret_cast<__m128i *>(out + 64 * xw + 16 * k), _mm_unpacklo_epi8(a, b));
+                if (STREAM) _mm_stream_si128(reinterpret_cast<__m128i *>(out + 64 * xw + 16 * k), _mm_unpacklo_epi8(a, b));
+                else _mm_storeu_si128(reinterpret_cast<__m128i *>(out + 64 * xw + 16 * k), _mm_unpacklo_epi8(a, b));
             }
         }
     }
+    if (STREAM) _mm_sfence();
+}
+
+void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins)
+{
+    if ((reinterpret_cast<uintptr_t>(spins) & 15u) == 0) unpack_lattice_impl<true>(W, H, words, spins); // rows are multiples of 64 bytes
+    else unpack_lattice_impl<false>(W, H, words, spins);
 }
 
 } // namespace isingmc

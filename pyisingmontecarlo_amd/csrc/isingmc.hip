@@ -2,6 +2,7 @@
 // Host orchestration only -- every Monte-Carlo operation runs in the kernels of
 // lattice_kernels.hpp / general_kernels.hpp.  There is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <cmath>
@@ -120,6 +121,14 @@ struct isingmc_states {
     uint32_t strip_epoch = 0;
     unsigned long long *d_strip_fin = nullptr; // [cap] final-measurement counters of the strip kernel (zero between launches)
     bool meas_fresh = false; // the tempering send buffer holds the energies of the CURRENT configurations (written by the last strip launch)
+    // sampling pipeline (isingmc_run_sampling): two slabs of samples in flight
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t sample_ready[2] = {nullptr, nullptr}, sample_copied[2] = {nullptr, nullptr};
+    uint32_t *d_samples[2] = {nullptr, nullptr}, *h_samples[2] = {nullptr, nullptr}; // h_*: pinned
+    unsigned long long *d_sample_counts[2] = {nullptr, nullptr}, *h_counts[2] = {nullptr, nullptr};
+    double *d_sample_e[2] = {nullptr, nullptr}, *h_e[2] = {nullptr, nullptr};
+    long long *d_sample_m = nullptr;
+    size_t sample_cap_words = 0, sample_cap_counts = 0, sample_cap_e = 0;
     // on-stream parallel tempering (isingmc_pt_*)
     bool pt_attached = false;
     PtDev pt{};
@@ -137,6 +146,16 @@ struct isingmc_states {
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
         if (d_tab) (void)hipFree(d_tab);
+        for (int b = 0; b < 2; b++) {
+            for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
+                if (p) (void)hipFree(p);
+            for (void *p : {(void *)h_samples[b], (void *)h_counts[b], (void *)h_e[b]})
+                if (p) (void)hipHostFree(p);
+            if (sample_ready[b]) (void)hipEventDestroy(sample_ready[b]);
+            if (sample_copied[b]) (void)hipEventDestroy(sample_copied[b]);
+        }
+        if (d_sample_m) (void)hipFree(d_sample_m);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (d_halo) (void)hipFree(d_halo);
         if (d_strip_err) (void)hipFree(d_strip_err);
         if (d_strip_fin) (void)hipFree(d_strip_fin);
@@ -1625,6 +1644,58 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
     return ISINGMC_OK;
 }
 
+// buffers of the sampling pipeline, grown on demand and kept for the next call (pinning host memory is slow)
+template <typename T>
+static int regrow(T **dev, T **host, size_t count)
+{
+    if (*dev) HIP_TRY(hipFree(*dev));
+    if (*host) HIP_TRY(hipHostFree(*host));
+    *dev = nullptr;
+    *host = nullptr;
+    TRY(dev_alloc(dev, count));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(host), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    return ISINGMC_OK;
+}
+
+static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies)
+{
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        if (!s->sample_ready[b]) HIP_TRY(hipEventCreateWithFlags(&s->sample_ready[b], hipEventDisableTiming));
+        if (!s->sample_copied[b]) HIP_TRY(hipEventCreateWithFlags(&s->sample_copied[b], hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    if (words > s->sample_cap_words) {
+        s->sample_cap_words = 0;
+        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_samples[b], &s->h_samples[b], words));
+        s->sample_cap_words = words;
+    }
+    if (counts > s->sample_cap_counts) {
+        s->sample_cap_counts = 0;
+        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_sample_counts[b], &s->h_counts[b], counts));
+        s->sample_cap_counts = counts;
+    }
+    if (energies > s->sample_cap_e) {
+        s->sample_cap_e = 0;
+        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_sample_e[b], &s->h_e[b], energies));
+        if (s->d_sample_m) HIP_TRY(hipFree(s->d_sample_m));
+        s->d_sample_m = nullptr;
+        TRY(dev_alloc(&s->d_sample_m, energies));
+        s->sample_cap_e = energies;
+    }
+    return ISINGMC_OK;
+}
+
+// large output arrays are touched for the first time by the expansion threads: with transparent huge pages the first
+// touch costs one fault per 2 MiB instead of one per 4 KiB (a hint; ignored where THP is off)
+static void madvise_hugepages(void *p, size_t bytes)
+{
+    if (bytes < (size_t(32) << 20)) return;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + 0x1FFFFF) & ~uintptr_t(0x1FFFFF);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~uintptr_t(0x1FFFFF);
+    if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+}
+
 extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq,
                                     size_t n_samples, double *energies_out, uint8_t *states_out)
 {
@@ -1655,51 +1726,64 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
     }
     const bool counts = s->packed || g->kind == ISINGMC_KIND_LATTICE2D;
     const size_t words = s->packed ? s->groups * size_t(g->pk.n_pos) : R * g->state_words;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(S, (size_t(512) << 20) / (words * sizeof(uint32_t))));
     const size_t CS = s->packed ? s->pk_slots() : R; // counter pairs per sample
-    DeviceScratch scratch(s->stream);
-    uint32_t *d_samples = nullptr;
-    unsigned long long *d_counts = nullptr;
-    double *d_e = nullptr;
-    long long *d_m = nullptr;
-    TRY(scratch.alloc(&d_samples, chunk * words));
-    if (counts) TRY(scratch.alloc(&d_counts, chunk * CS * 2));
-    else {
-        TRY(scratch.alloc(&d_e, chunk * R));
-        TRY(scratch.alloc(&d_m, chunk * R));
-    }
-    std::vector<uint32_t> h_samples(chunk * words);
-    std::vector<unsigned long long> h_counts(counts ? chunk * CS * 2 : 0);
-    std::vector<double> h_e(counts ? 0 : chunk * R);
-    for (size_t k0 = 0; k0 < S; k0 += chunk) {
-        const size_t nk = std::min(chunk, S - k0);
-        for (size_t k = 0; k < nk; k++) {
-            TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
-            HIP_TRY(hipMemcpyAsync(d_samples + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-            TRY(measure_enqueue(s, counts ? d_counts + k * CS * 2 : nullptr, counts ? nullptr : d_e + k * R, counts ? nullptr : d_m + k * R));
-        }
-        HIP_TRY(hipMemcpyAsync(h_samples.data(), d_samples, nk * words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-        if (counts) HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
-        else HIP_TRY(hipMemcpyAsync(h_e.data(), d_e, nk * R * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+    // Pipeline over SLABS of samples (<= 64 MiB of packed words each), two in flight: while the host expands
+    // slab j-1 from pinned memory into the caller's bool[R,S,N] array (non-temporal stores, all host threads), the device
+    // runs the sweeps of slab j and a second stream copies finished slabs out.  The expansion to one byte per spin is the
+    // floor of this call (the reference's output format: 8x the packed bytes, host memory bandwidth); the sweeps, the
+    // sample copies and PCIe hide behind it, or it hides behind them when sampling_freq is large.
+    const size_t slab_bytes = size_t(std::max(1, env_int("ISINGMC_SAMPLE_SLAB_BYTES", 64 << 20))); // (tests shrink it)
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(S, slab_bytes / (words * sizeof(uint32_t))));
+    const size_t n_slabs = (S + slab - 1) / slab;
+    TRY(sampling_reserve(s, slab * words, counts ? slab * CS * 2 : 0, counts ? 0 : slab * R));
+    madvise_hugepages(states_out, R * S * N);
+    const auto unpack_slab = [&](size_t j) {
+        const size_t k0 = j * slab, nk = std::min(slab, S - k0), b = j & 1;
+        const uint32_t *h_samples = s->h_samples[b];
+        const unsigned long long *h_counts = s->h_counts[b];
+        const double *h_e = s->h_e[b];
         parallel_for(nk * R, [&](size_t idx) {
             const size_t k = idx / R, r = idx % R;
             uint8_t *out = states_out + (r * S + k0 + k) * N;
             double energy;
             if (s->packed) {
                 const size_t sl = r + s->pk_bit0;
-                const uint32_t *w = h_samples.data() + k * words + (sl / 32) * g->pk.n_pos;
+                const uint32_t *w = h_samples + k * words + (sl / 32) * g->pk.n_pos;
                 const uint32_t bit = uint32_t(sl % 32);
                 for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
                 energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * CS + sl) * 2]))) + g->self_energy;
             } else {
-                unpack_state(g, h_samples.data() + k * words + r * g->state_words, out);
+                unpack_state(g, h_samples + k * words + r * g->state_words, out);
                 if (counts) energy = g->jabs * double(2 * int64_t(N) - 2 * int64_t(h_counts[(k * R + r) * 2]));
                 else energy = h_e[k * R + r] + g->self_energy;
             }
             energies_out[r * S + k0 + k] = energy;
         });
+    };
+    for (size_t j = 0; j < n_slabs; j++) {
+        const size_t k0 = j * slab, nk = std::min(slab, S - k0), b = j & 1;
+        // device slab b is free: its copy-out (slab j-2) was awaited before slab j-2 was expanded, in iteration j-1
+        for (size_t k = 0; k < nk; k++) {
+            TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
+            HIP_TRY(hipMemcpyAsync(s->d_samples[b] + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+            TRY(measure_enqueue(s, counts ? s->d_sample_counts[b] + k * CS * 2 : nullptr, counts ? nullptr : s->d_sample_e[b] + k * R,
+                                counts ? nullptr : s->d_sample_m));
+        }
+        HIP_TRY(hipEventRecord(s->sample_ready[b], s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->sample_ready[b], 0));
+        HIP_TRY(hipMemcpyAsync(s->h_samples[b], s->d_samples[b], nk * words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
+        if (counts) HIP_TRY(hipMemcpyAsync(s->h_counts[b], s->d_sample_counts[b], nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->copy_stream));
+        else HIP_TRY(hipMemcpyAsync(s->h_e[b], s->d_sample_e[b], nk * R * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_TRY(hipEventRecord(s->sample_copied[b], s->copy_stream));
+        if (j >= 1) { // expand the previous slab while the device works on this one
+            HIP_TRY(hipEventSynchronize(s->sample_copied[1 - b]));
+            unpack_slab(j - 1);
+        }
     }
+    HIP_TRY(hipEventSynchronize(s->sample_copied[(n_slabs - 1) & 1]));
+    unpack_slab(n_slabs - 1);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    TRY(strip_check(s));
     return ISINGMC_OK;
 }
 

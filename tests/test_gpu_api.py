@@ -442,6 +442,36 @@ def test_run_sampling_equals_step_by_step_loop(capi, exact, monkeypatch, kind):
     assert e0.shape == (R, 0) and a.timestep == 15
 
 
+@pytest.mark.parametrize("kind", ["lattice", "general", "packed"])
+def test_sampling_pipeline_slabs(capi, exact, monkeypatch, kind):
+    """isingmc_run_sampling works through slabs of samples, two in flight (device sweeps + copy-out of slab j while the
+    host expands slab j-1).  One sample per slab, an odd number of slabs, and the default (everything in one slab)
+    must give the same arrays."""
+    if kind == "lattice":
+        ea, eb, ej = exact.square_lattice_edges(1024, 64, -1.0)
+    elif kind == "general":
+        ea, eb, ej = exact.square_lattice_edges(30, 20, -1.0, np.random.default_rng(2))
+    else:
+        monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+        ea, eb, ej = exact.cubic_lattice_edges(10, -1.0)
+    g = capi.Graph(ea, eb, ej, force_general=kind != "lattice")
+    seeds = capi.make_seeds(4, 5)
+    out = []
+    for slab_bytes in (None, "1", str(3 * 5 * g.state_words * 4)):      # default / 1 sample per slab / 3 per slab (7 = 3 + 3 + 1)
+        if slab_bytes is None:
+            monkeypatch.delenv("ISINGMC_SAMPLE_SLAB_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("ISINGMC_SAMPLE_SLAB_BYTES", slab_bytes)
+        st = capi.States(g, seeds)
+        e, s = st.run_sampling(0.45, 3, 2, 7)
+        e2, s2 = st.run_sampling(0.45, 0, 1, 2)                          # the buffers are reused by the next call
+        out.append((e, s, e2, s2, st.energies()))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            np.testing.assert_array_equal(a, b)
+    assert np.array_equal(out[0][4], out[0][2][:, -1])                   # the last sample is the current configuration
+
+
 @pytest.mark.parametrize("kind", ["csr_streaming", "packed"])
 def test_per_step_energies_equal_step_by_step_measurements(capi, exact, monkeypatch, kind):
     """Energies after every timestep (lattice.rs:445-455) on the non-resident CSR path and on the replica-packed
