@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ISINGMC_ABI_VERSION 1
+#define ISINGMC_ABI_VERSION 2
 
 enum {
     ISINGMC_OK = 0,
@@ -39,7 +39,7 @@ enum {
 /* graph kinds reported by isingmc_graph_info */
 enum {
     ISINGMC_KIND_GENERAL = 0,  /* greedy-coloured CSR path, any edge list */
-    ISINGMC_KIND_LATTICE2D = 1 /* periodic W x H square lattice, uniform |J|: checkerboard path */
+    ISINGMC_KIND_LATTICE2D = 1 /* W x H square lattice, uniform |J|, periodic or open, optional uniform field: checkerboard path */
 };
 
 /* isingmc_graph_create flags */
@@ -60,6 +60,10 @@ typedef struct {
     int32_t uniform_sign;/* LATTICE2D: 1 if every bond has the same sign */
     uint32_t n_colours;  /* independent sets per timestep (2 on the lattice path) */
     uint64_t state_words;/* 32-bit words of packed spin state per replica */
+    int32_t fast_path;   /* LATTICE2D: 0 = periodic, no field; 1 = uniform field (set_global_bias, lattice.rs:129-131;
+                            ClassicIsing longitudinal, classicising.rs:69); 2 = open boundaries */
+    int32_t open_x, open_y; /* LATTICE2D: no bonds between columns W-1 and 0 / rows H-1 and 0 */
+    double field;        /* LATTICE2D: the uniform bias h of E = sum J s s - h sum s (0 without) */
 } isingmc_graph_info_t;
 
 const char *isingmc_last_error(void);
@@ -79,8 +83,9 @@ int isingmc_host_make_seeds(int has_seed, uint64_t seed_gen, size_t n, uint64_t 
 int isingmc_host_expand_schedule(const uint64_t *stop_t, const double *stop_beta, size_t n_stops,
                                  size_t timesteps, int compat_constant_beta, double *betas_out);
 
-/* Recogniser: is this edge list a periodic W x H square lattice with ids y*W+x, every bond
- * present once, uniform |J|?  *is_lattice = 0 when not (then the general path is used). */
+/* Recogniser: is this edge list a W x H square lattice with ids y*W+x, every bond present once,
+ * uniform |J|, periodic or open (ALL wrap-around bonds of a direction absent) in each direction?
+ * *is_lattice = 0 when not (then the general path is used), else 1 + 2 (open in x) + 4 (open in y). */
 int isingmc_host_recognise_lattice2d(const uint64_t *edge_a, const uint64_t *edge_b,
                                      const double *edge_j, size_t n_edges, size_t nvars,
                                      int *is_lattice, int *width, int *height, double *jabs,

@@ -384,33 +384,40 @@ static int bond_pos(const uint8_t *plane, int jpos_uniform, int W, int y, int x)
     return plane ? plane[(size_t)y * W + x] : jpos_uniform;
 }
 
-/* number of satisfied bonds (J s s < 0) of site (y,x) */
-static int lat_satisfied(const lat_geom *g, const uint32_t *state, const uint8_t *jright,
-                         const uint8_t *jdown, int jpos_uniform, int y, int x)
+/* satisfied (J s s < 0) and unsatisfied bonds of site (y,x) among the bonds that EXIST: with open boundaries in x
+ * (open_x) the bonds between columns W-1 and 0 are absent, with open_y those between rows H-1 and 0 */
+static void lat_bond_counts(const lat_geom *g, const uint32_t *state, const uint8_t *jright,
+                            const uint8_t *jdown, int jpos_uniform, int open_x, int open_y, int y, int x,
+                            int *sat, int *unsat)
 {
     int W = g->W, H = g->H;
     int s = lat_get(g, state, y, x);
     int xl = (x + W - 1) % W, xr = (x + 1) % W, yu = (y + H - 1) % H, yd = (y + 1) % H;
-    int k = 0;
+    int k = 0, u = 0, ok;
     /* a bond with J>0 is satisfied when the spins differ, with J<0 when they agree */
-    k += (s != lat_get(g, state, y, xr)) == bond_pos(jright, jpos_uniform, W, y, x);
-    k += (s != lat_get(g, state, y, xl)) == bond_pos(jright, jpos_uniform, W, y, xl);
-    k += (s != lat_get(g, state, yd, x)) == bond_pos(jdown, jpos_uniform, W, y, x);
-    k += (s != lat_get(g, state, yu, x)) == bond_pos(jdown, jpos_uniform, W, yu, x);
-    return k;
+    if (!(open_x && x == W - 1)) { ok = (s != lat_get(g, state, y, xr)) == bond_pos(jright, jpos_uniform, W, y, x); k += ok; u += !ok; }
+    if (!(open_x && x == 0)) { ok = (s != lat_get(g, state, y, xl)) == bond_pos(jright, jpos_uniform, W, y, xl); k += ok; u += !ok; }
+    if (!(open_y && y == H - 1)) { ok = (s != lat_get(g, state, yd, x)) == bond_pos(jdown, jpos_uniform, W, y, x); k += ok; u += !ok; }
+    if (!(open_y && y == 0)) { ok = (s != lat_get(g, state, yu, x)) == bond_pos(jdown, jpos_uniform, W, yu, x); k += ok; u += !ok; }
+    *sat = k;
+    *unsat = u;
 }
 
 /*
- * S3: one timestep t = colour 0 pass then colour 1 pass.  Flipping a spin with k satisfied
- * bonds costs dE = 2|J|(2k-4): k<=2 always flips, k=3 / k=4 flip iff u < T3 / T4 with
- * u = (N_PLANES-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only
- * when the prefix equals the threshold's top N_PLANES bits: a "tie").
+ * S3: one timestep t = colour 0 pass then colour 1 pass.  A spin s (+1 for a set bit) with `sat` satisfied and
+ * `unsat` unsatisfied bonds in a uniform field h (E = sum J s s - h sum s, lattice.rs:129-131 set_global_bias,
+ * classicising.rs:69 longitudinal) costs dE = 2|J|(sat - unsat) + 2 h s to flip; with T = fixed(exp(-beta dE))
+ * (2^THR_BITS = always, in particular whenever dE <= 0) it flips iff u < T, where
+ * u = (N_PLANES-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only when T is not
+ * "always" and the prefix equals the threshold's top N_PLANES bits: a "tie"; the n-th tie of the quad in (word, bit)
+ * order takes word n%4 of call N_PLANES + n/4).  Periodic, h = 0: dE = 2|J|(2k-4), the k = 3, 4 classes of round 1.
  */
-void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
-                   const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)
+void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                      const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
+                      uint64_t t, double beta)
 {
     lat_geom g = lat_make(W, H);
-    uint64_t T3 = orc_threshold_fixed(beta, 4.0 * jabs), T4 = orc_threshold_fixed(beta, 8.0 * jabs);
+    const uint64_t ONE = (uint64_t)1 << THR_BITS;
     size_t nquads = g.wpp / 4;
     for (uint32_t c = 0; c < 2; c++) {
         uint32_t *own = state + c * g.wpp;
@@ -428,11 +435,14 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
                 for (int b = 0; b < 32; b++) {
                     int i = 32 * xw + b;
                     int x = 2 * i + ((y + (int)c) & 1);
-                    int k = lat_satisfied(&g, state, jright, jdown, jpos_uniform, y, x);
+                    int sat, unsat;
+                    lat_bond_counts(&g, state, jright, jdown, jpos_uniform, open_x, open_y, y, x, &sat, &unsat);
+                    double sval = lat_get(&g, state, y, x) ? 1.0 : -1.0;
+                    double dE = 2.0 * jabs * (double)(sat - unsat) + 2.0 * h * sval;
+                    uint64_t T = orc_threshold_fixed(beta, dE);
                     int accept;
-                    if (k <= 2) accept = 1;
+                    if (T == ONE) accept = 1;
                     else {
-                        uint64_t T = (k == 3) ? T3 : T4;
                         uint32_t hi = (uint32_t)(T >> 32), lo = (uint32_t)T;
                         uint32_t upre = 0;
                         for (int p = 0; p < N_PLANES; p++)
@@ -456,9 +466,16 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
     }
 }
 
-/* E = sum over bonds of J s s (J = +-jabs) and M = sum s, from the packed state */
-void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
-                        const uint8_t *jdown, const uint32_t *state, double *energy, int64_t *mag)
+void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                   const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)
+{
+    orc_lat_sweep_ex(W, H, jabs, jpos_uniform, jright, jdown, 0.0, 0, 0, state, seed, t, beta);
+}
+
+/* E = sum over existing bonds of J s s (J = +-jabs) - h sum s, and M = sum s, from the packed state */
+void orc_lat_energy_mag_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                           const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
+                           double *energy, int64_t *mag)
 {
     lat_geom g = lat_make(W, H);
     int64_t unsat_minus_sat = 0, m = 0;
@@ -467,11 +484,20 @@ void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8
             int s = lat_get(&g, state, y, x);
             m += s ? 1 : -1;
             int sr = lat_get(&g, state, y, (x + 1) % W), sd = lat_get(&g, state, (y + 1) % H, x);
-            unsat_minus_sat += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
-            unsat_minus_sat += ((s != sd) == bond_pos(jdown, jpos_uniform, W, y, x)) ? -1 : 1;
+            if (!(open_x && x == W - 1))
+                unsat_minus_sat += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
+            if (!(open_y && y == H - 1))
+                unsat_minus_sat += ((s != sd) == bond_pos(jdown, jpos_uniform, W, y, x)) ? -1 : 1;
         }
-    if (energy) *energy = jabs * (double)unsat_minus_sat;
+    /* the two terms separately, then one subtraction: the engine forms the same expression from its counters */
+    if (energy) *energy = jabs * (double)unsat_minus_sat - h * (double)m;
     if (mag) *mag = m;
+}
+
+void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                        const uint8_t *jdown, const uint32_t *state, double *energy, int64_t *mag)
+{
+    orc_lat_energy_mag_ex(W, H, jabs, jpos_uniform, jright, jdown, 0.0, 0, 0, state, energy, mag);
 }
 
 /* ==========================================================================================

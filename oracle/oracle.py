@@ -54,6 +54,10 @@ def lib():
         L.orc_lat_energy_mag.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                          C.c_void_p, u32p, C.POINTER(C.c_double),
                                          C.POINTER(C.c_int64)]
+        L.orc_lat_sweep_ex.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                       C.c_int, u32p, C.c_uint64, C.c_uint64, C.c_double]
+        L.orc_lat_energy_mag_ex.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_int, C.c_int, u32p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.orc_det_exp.restype = C.c_double
         L.orc_det_exp.argtypes = [C.c_double]
         L.orc_gen_colouring.restype = C.c_uint32
@@ -141,9 +145,11 @@ def det_exp(x):
 class Lat:
     """Checkerboard spec engine (engine B) for one replica of a periodic W x H lattice."""
 
-    def __init__(self, W, H, jabs=1.0, jpos_uniform=0, jright=None, jdown=None):
+    def __init__(self, W, H, jabs=1.0, jpos_uniform=0, jright=None, jdown=None, field=0.0, open_x=False, open_y=False):
+        """field: uniform h of E = sum J s s - h sum s; open_x / open_y: no bonds between columns W-1 and 0 / rows H-1 and 0."""
         assert lib().orc_lat_supported(W, H), (W, H)
         self.W, self.H, self.jabs, self.jpos = W, H, float(jabs), int(jpos_uniform)
+        self.field, self.open_x, self.open_y = float(field), int(bool(open_x)), int(bool(open_y))
         self.jright = None if jright is None else np.ascontiguousarray(jright, dtype=np.uint8)
         self.jdown = None if jdown is None else np.ascontiguousarray(jdown, dtype=np.uint8)
         self.words = lib().orc_lat_state_words(W, H)
@@ -164,14 +170,13 @@ class Lat:
         return out
 
     def sweep(self, st, seed, t, beta):
-        lib().orc_lat_sweep(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright),
-                            _ptr(self.jdown), st, C.c_uint64(int(seed)), C.c_uint64(int(t)),
-                            float(beta))
+        lib().orc_lat_sweep_ex(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright), _ptr(self.jdown), self.field,
+                               self.open_x, self.open_y, st, C.c_uint64(int(seed)), C.c_uint64(int(t)), float(beta))
 
     def energy_mag(self, st):
         e, m = C.c_double(), C.c_int64()
-        lib().orc_lat_energy_mag(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright),
-                                 _ptr(self.jdown), st, C.byref(e), C.byref(m))
+        lib().orc_lat_energy_mag_ex(self.W, self.H, self.jabs, self.jpos, _ptr(self.jright), _ptr(self.jdown), self.field,
+                                    self.open_x, self.open_y, st, C.byref(e), C.byref(m))
         return e.value, m.value
 
 

@@ -83,8 +83,8 @@ Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const doub
 {
     Lattice2D out;
     const uint64_t N = nvars;
-    if (N < 16 || n_edges != 2 * N || N > (uint64_t(1) << 40)) return out;
-    // |a-b| is 1 or W-1 for horizontal bonds, W or N-W for vertical ones; N-W of the 2N bonds
+    if (N < 16 || n_edges > 2 * N || n_edges < N || N > (uint64_t(1) << 40)) return out;
+    // |a-b| is 1 or W-1 for horizontal bonds, W or N-W for vertical ones; N-W of the bonds
     // have |a-b| == W, which makes W the most frequent difference other than 1.
     std::unordered_map<uint64_t, uint64_t> hist;
     for (size_t k = 0; k < n_edges; k++) {
@@ -118,10 +118,23 @@ Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const doub
         jpos[slot] = pos;
         (pos ? any_pos : any_neg) = true;
     }
+    // every interior bond once; the bonds that wrap around in x (right bonds of column W-1) and in y (down bonds of row
+    // H-1) either all present (periodic) or all absent (open boundary) in each direction
+    uint64_t wrap_x = 0, wrap_y = 0;
+    for (uint64_t i = 0; i < N; i++) {
+        const bool last_col = i % W == W - 1, last_row = i >= N - W;
+        if (last_col) wrap_x += seen[2 * i];
+        else if (!seen[2 * i]) return out;
+        if (last_row) wrap_y += seen[2 * i + 1];
+        else if (!seen[2 * i + 1]) return out;
+    }
+    if ((wrap_x != 0 && wrap_x != H) || (wrap_y != 0 && wrap_y != W)) return out;
     out.ok = true;
     out.W = int(W);
     out.H = int(H);
     out.jabs = jabs;
+    out.open_x = wrap_x == 0;
+    out.open_y = wrap_y == 0;
     out.uniform_sign = !(any_pos && any_neg);
     out.jpos_uniform = any_pos && !any_neg;
     if (!out.uniform_sign) {

@@ -28,6 +28,7 @@ struct Lattice2D {
     double jabs = 0.0;
     bool uniform_sign = true;
     bool jpos_uniform = false;          // sign when uniform: true = J > 0 (antiferromagnetic)
+    bool open_x = false, open_y = false; // no bonds between columns W-1 and 0 / rows H-1 and 0 (all of them absent)
     std::vector<uint8_t> jright, jdown; // per site: 1 if that bond has J > 0 (empty when uniform)
 };
 

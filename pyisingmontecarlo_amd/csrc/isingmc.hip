@@ -21,6 +21,7 @@
 #include "host_logic.hpp"
 #include "lattice_kernels.hpp"
 #include "packed_kernels.hpp"
+#include "mc_types.hpp"
 #include "strip_types.hpp"
 
 using namespace isingmc;
@@ -66,6 +67,10 @@ struct isingmc_graph {
     bool uniform_sign = true;
     uint32_t jneg_uniform = 0;
     uint32_t *d_jneg = nullptr; // [2 colours][4 directions][wpp]
+    // multi-class checkerboard kernels (mc_types.hpp): uniform field or open boundaries on a recognised lattice
+    int mc_mode = MC_NONE;
+    double field = 0.0;   // MC_FIELD: h of E = sum J s s - h sum s
+    McOpen open{0, 0};    // MC_OPEN
     // general path
     GenGraphDev gdev{};
     bool w_is_float = false;
@@ -101,6 +106,7 @@ struct isingmc_states {
     bool has_betas = false;
     std::vector<double> betas;
     LatThr *d_thr = nullptr;
+    LatThrMC *d_thr_mc = nullptr; // per-replica thresholds of the multi-class kernels (has_betas on a field / open lattice)
     double *d_beta = nullptr;
     // measurement scratch
     unsigned long long *d_meas = nullptr; // lattice: [R][2]
@@ -146,6 +152,7 @@ struct isingmc_states {
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
         if (d_tab) (void)hipFree(d_tab);
+        if (d_thr_mc) (void)hipFree(d_thr_mc);
         for (int b = 0; b < 2; b++) {
             for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
                 if (p) (void)hipFree(p);
@@ -246,6 +253,36 @@ static uint64_t threshold_fixed(double beta, double dE)
 static LatThr lattice_thresholds(double beta, double jabs)
 {
     return LatThr{threshold_fixed(beta, 4.0 * jabs), threshold_fixed(beta, 8.0 * jabs)};
+}
+
+// thresholds of the multi-class kernels (classes: mc_types.hpp); same fixed-point rule, same exp as the two-class ones
+static LatThrMC lattice_thresholds_mc(const isingmc_graph *g, double beta)
+{
+    LatThrMC t{};
+    const int nc = g->mc_mode == MC_FIELD ? 6 : 4;
+    for (int c = 0; c < nc; c++) {
+        double dE;
+        if (g->mc_mode == MC_FIELD) {
+            const int k = 2 + c / 2;
+            const double sval = (c & 1) ? 1.0 : -1.0;
+            dE = 2.0 * g->jabs * double(2 * k - 4) + 2.0 * g->field * sval; // the oracle's expression: 2|J|(sat - unsat) + 2 h s
+        } else {
+            dE = 2.0 * g->jabs * double(c + 1);
+        }
+        const uint64_t T = threshold_fixed(beta, dE);
+        if (!(T >> THR_BITS)) t.costly |= 1u << c;
+        t.hi[c] = uint32_t(T >> 32) & ((1u << N_PLANES) - 1);
+        t.lo[c] = uint32_t(T);
+    }
+    return t;
+}
+
+// lattice energy from the integer counters: E = |J| (bonds - 2 satisfied) - h (2 up - N)   (exact in f64 for h = 0)
+static double lattice_energy(const isingmc_graph *g, unsigned long long sat, unsigned long long up)
+{
+    const double bonds = g->jabs * double(int64_t(g->n_edges) - 2 * int64_t(sat));
+    if (g->mc_mode != MC_FIELD) return bonds;
+    return bonds - g->field * double(2 * int64_t(up) - int64_t(g->nvars));
 }
 
 template <typename F>
@@ -349,7 +386,7 @@ extern "C" int isingmc_host_recognise_lattice2d(const uint64_t *ea, const uint64
     if (!is_lattice) return fail(ISINGMC_ERR_INVALID, "is_lattice is NULL");
     TRY(check_edges(ea, eb, ej, n_edges, nvars));
     const Lattice2D L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    *is_lattice = L.ok;
+    *is_lattice = L.ok ? 1 + 2 * int(L.open_x) + 4 * int(L.open_y) : 0; // bit 0: a W x H lattice; bits 1, 2: open in x, y
     if (width) *width = L.W;
     if (height) *height = L.H;
     if (jabs) *jabs = L.jabs;
@@ -383,18 +420,38 @@ extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t 
 // ------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------
-static bool lattice_fast_path_ok(const Lattice2D &L)
+// the uniform field h (0 without), or NaN when the biases differ from site to site
+static double uniform_bias(const double *biases, size_t nvars)
+{
+    if (!biases) return 0.0;
+    for (size_t i = 1; i < nvars; i++)
+        if (biases[i] != biases[0]) return std::numeric_limits<double>::quiet_NaN();
+    return biases[0];
+}
+
+// Periodic and field-free: the two-class kernels of lattice_kernels.hpp.  A uniform field |h| <= 2|J| on a periodic
+// lattice, or open boundaries without a field: the multi-class kernels (whole quads per row needed).  Anything else
+// (site-dependent biases, a field on an open lattice, |h| > 2|J|): the general path.
+static bool lattice_fast_path_ok(const Lattice2D &L, double h)
 {
     if (!L.ok || L.W % 64 != 0) return false;
+    if (std::isnan(h)) return false;
+    const bool open = L.open_x || L.open_y;
+    if (open && h != 0.0) return false;
+    if (h != 0.0 && !(std::fabs(h) <= 2.0 * L.jabs)) return false;
+    if ((open || h != 0.0) && (L.W / 64) % 4 != 0) return false;
     const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
     // the kernels address a replica through ONE buffer descriptor (int num_records) and 32-bit byte offsets:
     // both planes must fit below 2^31 bytes; larger lattices take the general path
     return wpp % 4 == 0 && 2 * wpp * sizeof(uint32_t) < (uint64_t(1) << 31);
 }
 
-static int build_lattice(isingmc_graph *g, const Lattice2D &L)
+static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h)
 {
     g->kind = ISINGMC_KIND_LATTICE2D;
+    g->mc_mode = h != 0.0 ? MC_FIELD : (L.open_x || L.open_y) ? MC_OPEN : MC_NONE;
+    g->field = h;
+    g->open = McOpen{uint32_t(L.open_x), uint32_t(L.open_y)};
     LatGeom &G = g->geom;
     G.W = L.W;
     G.H = L.H;
@@ -568,8 +625,9 @@ extern "C" int isingmc_graph_create(const uint64_t *ea, const uint64_t *eb, cons
     g->n_edges = n_edges;
     g->has_bias = has_bias;
     Lattice2D L;
-    if (!(flags & ISINGMC_FLAG_FORCE_GENERAL) && !has_bias) L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    if (lattice_fast_path_ok(L)) TRY(build_lattice(g.get(), L));
+    const double h = has_bias ? uniform_bias(biases, nvars) : 0.0;
+    if (!(flags & ISINGMC_FLAG_FORCE_GENERAL) && !std::isnan(h)) L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
+    if (lattice_fast_path_ok(L, h)) TRY(build_lattice(g.get(), L, h));
     else TRY(build_general(g.get(), ea, eb, ej, n_edges, nvars, biases));
     *graph_out = g.release();
     return ISINGMC_OK;
@@ -588,6 +646,10 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
         info->height = int32_t(g->geom.H);
         info->jabs = g->jabs;
         info->uniform_sign = g->uniform_sign;
+        info->fast_path = g->mc_mode;
+        info->field = g->field;
+        info->open_x = int32_t(g->open.open_x);
+        info->open_y = int32_t(g->open.open_y);
     }
     info->n_colours = g->n_colours;
     info->state_words = g->state_words;
@@ -790,7 +852,14 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
         s->has_betas = true;
         return ISINGMC_OK;
     }
-    if (s->g->kind == ISINGMC_KIND_LATTICE2D) {
+    if (s->g->kind == ISINGMC_KIND_LATTICE2D && s->g->mc_mode != MC_NONE) {
+        std::vector<LatThrMC> thr(s->R);
+        for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds_mc(s->g, s->betas[r]);
+        if (s->d_thr_mc) HIP_TRY(hipFree(s->d_thr_mc));
+        s->d_thr_mc = nullptr;
+        TRY(dev_alloc(&s->d_thr_mc, s->cap));
+        if (s->R) HIP_TRY(hipMemcpyAsync(s->d_thr_mc, thr.data(), s->R * sizeof(LatThrMC), hipMemcpyHostToDevice, s->stream));
+    } else if (s->g->kind == ISINGMC_KIND_LATTICE2D) {
         std::vector<LatThr> thr(s->R);
         for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds(s->betas[r], s->g->jabs);
         if (s->R) HIP_TRY(hipMemcpyAsync(s->d_thr, thr.data(), s->R * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
@@ -1113,6 +1182,11 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
     for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
         const size_t n = std::min(MAX_GRID_Y, s->R - r0);
         const uint32_t blocks = (g->geom.nquads + 256 * MEASURE_QUADS_PER_THREAD - 1) / (256 * MEASURE_QUADS_PER_THREAD);
+        if (g->mc_mode == MC_OPEN) { // the bonds across the open boundary do not exist: they must not count as satisfied
+            (void)mc_launch_measure_open(PMJ, dim3(blocks, unsigned(n)), s->stream, s->d_state + r0 * g->state_words, g->geom, g->d_jneg,
+                                         g->jneg_uniform, g->open, out + r0 * out_stride, out_stride);
+            continue;
+        }
         hipLaunchKernelGGL((lat_measure_kernel<VEC, PMJ>), dim3(blocks, unsigned(n)), dim3(256), 0, s->stream,
                            s->d_state + r0 * g->state_words, g->geom, g->d_jneg, g->jneg_uniform,
                            out + r0 * out_stride, out_stride);
@@ -1200,9 +1274,8 @@ static int measure(isingmc_states *s, double *energies, int64_t *mags)
         std::vector<unsigned long long> h(2 * R);
         HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        const int64_t nbonds = 2 * int64_t(g->nvars);
         for (size_t r = 0; r < R; r++) {
-            if (energies) energies[r] = g->jabs * double(nbonds - 2 * int64_t(h[2 * r]));
+            if (energies) energies[r] = lattice_energy(g, h[2 * r], h[2 * r + 1]);
             if (mags) mags[r] = 2 * int64_t(h[2 * r + 1]) - int64_t(g->nvars);
         }
     } else {
@@ -1379,12 +1452,14 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // end of each chunk; on the general path one measure() per step.
     // small lattices: one LDS-resident launch per chunk of timesteps instead of two launches per timestep
     // (up to 1024 quads per colour: beyond that one workgroup per replica is slower than the launches it saves)
-    const bool resident = lattice && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
+    // lattices with a field or open boundaries: the multi-class kernels, one launch per colour (+ one measurement per step)
+    const bool mc = lattice && g->mc_mode != MC_NONE;
+    const bool resident = lattice && !mc && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
                           !resident_disabled();
     // per-step counters: 16 B per (step, replica) and counter slot, at most 32 MiB per chunk on each side of the bus
-    const StripPlan strip = (lattice && !resident) ? strip_plan(s, timesteps) : StripPlan{};
+    const StripPlan strip = (lattice && !resident && !mc) ? strip_plan(s, timesteps) : StripPlan{};
     s->meas_fresh = false;
-    const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use) ? MEASURE_SLOTS : 1;
+    const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use && !mc) ? MEASURE_SLOTS : 1;
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
     const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
     if (resident || gen_resident || strip.use) chunk = std::min<size_t>(chunk, 65536);
@@ -1413,7 +1488,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
     // replica blocks on several streams.  Large launches (c2) keep the chip full on one stream.
     size_t want_lanes = 1;
-    if (lattice && !resident && !strip.use && !energies_per_step) {
+    if (lattice && !resident && !strip.use && !mc && !energies_per_step) {
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
@@ -1491,7 +1566,24 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
         }
         for (size_t k = k0; k < k0 + nk && !resident && !gen_resident && !strip.use; k++) {
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
-            if (lattice) {
+            if (mc) {
+                const LatThrMC thr = lattice_thresholds_mc(g, beta);
+                for (uint32_t colour = 0; colour < 2 && rc == ISINGMC_OK; colour++)
+                    for (size_t r0 = 0; r0 < R; r0 += MAX_GRID_Y) {
+                        const size_t n = std::min(MAX_GRID_Y, R - r0);
+                        const hipError_t err = mc_launch_sweep(g->mc_mode, !g->uniform_sign, lat_grid(g, g->geom.nquads, n), s->stream,
+                                                               s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                                                               s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open);
+                        if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+                    }
+                if (rc != ISINGMC_OK) break;
+                if (d_steps) { // get_energy after this timestep: a measurement pass behind the sweep (as on the general path)
+                    s->t++;
+                    rc = measure_enqueue(s, d_steps + (k - k0) * R * 2, nullptr, nullptr);
+                    if (rc != ISINGMC_OK) break;
+                    continue;
+                }
+            } else if (lattice) {
                 const LatThr thr = lattice_thresholds(beta, g->jabs);
                 LAT_DISPATCH(launch_lat_sweep, s, 0u, thr, s->t);
                 if (d_steps) LAT_DISPATCH(launch_lat_sweep_measure, s, thr, s->t, d_steps + (k - k0) * R * 2 * step_slots, 2 * step_slots);
@@ -1517,12 +1609,14 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             hipError_t err = hipMemcpyAsync(h_steps.data(), d_steps, nk * R * 2 * step_slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
             if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
             if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
-            const int64_t nbonds = 2 * int64_t(g->nvars);
             for (size_t k = 0; k < nk; k++)
                 for (size_t r = 0; r < R; r++) {
-                    int64_t sat = 0;
-                    for (size_t sl = 0; sl < step_slots; sl++) sat += int64_t(h_steps[((k * R + r) * step_slots + sl) * 2]);
-                    energies_per_step[r * timesteps + k0 + k] = g->jabs * double(nbonds - 2 * sat);
+                    unsigned long long sat = 0, up = 0;
+                    for (size_t sl = 0; sl < step_slots; sl++) {
+                        sat += h_steps[((k * R + r) * step_slots + sl) * 2];
+                        up += h_steps[((k * R + r) * step_slots + sl) * 2 + 1];
+                    }
+                    energies_per_step[r * timesteps + k0 + k] = lattice_energy(g, sat, up);
                 }
         }
     }
@@ -1754,7 +1848,7 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
                 energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * CS + sl) * 2]))) + g->self_energy;
             } else {
                 unpack_state(g, h_samples + k * words + r * g->state_words, out);
-                if (counts) energy = g->jabs * double(2 * int64_t(N) - 2 * int64_t(h_counts[(k * R + r) * 2]));
+                if (counts) energy = lattice_energy(g, h_counts[(k * R + r) * 2], h_counts[(k * R + r) * 2 + 1]);
                 else energy = h_e[k * R + r] + g->self_energy;
             }
             energies_out[r * S + k0 + k] = energy;
@@ -1810,7 +1904,8 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
 {
     if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
-    if (s->g->kind != ISINGMC_KIND_LATTICE2D) return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path");
+    if (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE)
+        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for periodic, field-free lattices (use the host swap step)");
     if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
         return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
     for (size_t i = 0; i < n_rungs; i++)

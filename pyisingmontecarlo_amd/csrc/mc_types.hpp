@@ -1,0 +1,36 @@
+// Host-visible types and launchers of the multi-class checkerboard kernels (mc_kernels.hpp): recognised lattices with
+// a uniform field (Lattice.set_global_bias, lattice.rs:129-131; ClassicIsing(longitudinal), classicising.rs:69) or with
+// open boundaries.  A translation unit of their own, like the strip kernel (strip_types.hpp says why).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace isingmc {
+
+struct LatGeom;
+
+enum : int { MC_NONE = 0, MC_FIELD = 1, MC_OPEN = 2 };
+constexpr int MC_MAX_CLASSES = 6;
+
+// Acceptance classes of a spin.  MC_FIELD (periodic, |h| <= 2|J|): class 2 (k - 2) + s for k = 2, 3, 4 satisfied bonds
+// and spin bit s -- flipping costs dE = 2|J|(2k - 4) + 2 h (2s - 1); k < 2 always flips.  MC_OPEN (no field, bonds
+// across the open boundary absent): class m - 1 for m = satisfied - unsatisfied EXISTING bonds = 1 .. 4, dE = 2|J| m.
+// Per class: the top N_PLANES bits and the low 32 bits of T = floor(exp(-beta dE) 2^THR_BITS); bit c of `costly` is
+// clear where the class flips outright (dE <= 0 or T = 2^THR_BITS).
+struct LatThrMC {
+    uint32_t hi[MC_MAX_CLASSES], lo[MC_MAX_CLASSES];
+    uint32_t costly;
+};
+
+struct McOpen {
+    uint32_t open_x, open_y;
+};
+
+hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
+                           uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
+                           const uint32_t *jneg, uint32_t jneg_uniform, McOpen open);
+// satisfied EXISTING bonds and up spins per replica: out[r * stride] += sat, out[r * stride + 1] += up
+hipError_t mc_launch_measure_open(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
+                                  uint32_t jneg_uniform, McOpen open, unsigned long long *out, size_t out_stride);
+
+} // namespace isingmc

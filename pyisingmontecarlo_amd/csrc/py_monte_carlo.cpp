@@ -243,6 +243,9 @@ public:
         d["height"] = info.height;
         d["n_colours"] = info.n_colours;
         d["uniform_sign"] = bool(info.uniform_sign);
+        d["field"] = info.field;
+        d["open_x"] = bool(info.open_x);
+        d["open_y"] = bool(info.open_y);
         return d;
     }
 

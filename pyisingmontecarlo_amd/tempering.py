@@ -22,7 +22,7 @@ class HipEngine:
         self.graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=device)
         self.nvars = self.graph.nvars
         # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream
-        self.supports_on_stream_pt = self.graph.kind == _capi.KIND_LATTICE2D
+        self.supports_on_stream_pt = self.graph.kind == _capi.KIND_LATTICE2D and self.graph.info.fast_path == 0
 
     def make_states(self, seeds, replica_range=None):
         """seeds of ALL slots + this rank's [lo, hi): group membership on the replica-packed path follows the global

@@ -1,0 +1,189 @@
+"""recognised lattices with a uniform field (Lattice.set_global_bias, lattice.rs:129-131; ClassicIsing's
+longitudinal field, classicising.rs:69) or with open boundaries stay on the bit-sliced checkerboard path (multi-class
+kernels, csrc/mc_kernels.hpp) and must reproduce oracle engine B -- spin by spin, field and missing bonds included --
+bit for bit; energies E = sum J s s - h sum s from the integer counters."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+SEEDS = np.array([0x0123456789ABCDEF, 42, 2**64 - 1], dtype=np.uint64)
+
+
+def _edges(ea, eb, ej):
+    return [((int(a), int(b)), float(j)) for a, b, j in zip(ea, eb, ej)]
+
+
+def _open_lattice(exact, W, H, J, rng, open_x, open_y):
+    ea, eb, ej = exact.square_lattice_edges(W, H, J, rng)
+    keep = np.ones(len(ea), dtype=bool)
+    if open_x:
+        keep &= ~((ea % W == W - 1) & (eb % W == 0))                # right bonds of the last column
+    if open_y:
+        keep &= ~((ea // W == H - 1) & (eb // W == 0))              # down bonds of the last row
+    return ea, eb, ej, keep
+
+
+def _check(capi, oracle, g, lat, ea, eb, ej, nvars, biases, T, betas, seeds=SEEDS):
+    st = capi.States(g, seeds)
+    ref = [lat.init(s) for s in seeds]
+    np.testing.assert_array_equal(st.packed(), np.stack(ref))
+    eps = st.do_time_steps(T, betas, per_step_energies=True)
+    for r, s in enumerate(seeds):
+        for t in range(T):
+            lat.sweep(ref[r], s, t, betas[t] if np.ndim(betas) else betas)
+            assert eps[r, t] == lat.energy_mag(ref[r])[0], (r, t)
+    np.testing.assert_array_equal(st.packed(), np.stack(ref), err_msg="state after sweeps")
+    st.do_time_steps(3, 0.6)                                          # no per-step energies: the plain launches
+    for r, s in enumerate(seeds):
+        for t in range(T, T + 3):
+            lat.sweep(ref[r], s, t, 0.6)
+    np.testing.assert_array_equal(st.packed(), np.stack(ref))
+    em = [lat.energy_mag(x) for x in ref]
+    np.testing.assert_array_equal(st.energies(), [e for e, _ in em])
+    np.testing.assert_array_equal(st.magnetisations(), [m for _, m in em])
+    spins = st.states()
+    for r in range(len(seeds)):                                       # K1: energy recomputed from the returned spins
+        np.testing.assert_allclose(st.energies()[r], oracle.energy(ea, eb, ej, nvars, spins[r], biases=biases), rtol=1e-12, atol=1e-9)
+    return st
+
+
+@pytest.mark.parametrize("W,H", [(256, 16), (512, 32), (1024, 8)])
+@pytest.mark.parametrize("h", [0.25, -0.7, 2.0, -2.0])
+@pytest.mark.parametrize("glass", [False, True])
+def test_uniform_field_bit_exact(capi, oracle, exact, W, H, h, glass):
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0, np.random.default_rng(W) if glass else None)
+    biases = np.full(W * H, h)
+    g = capi.Graph(ea, eb, ej, biases=biases)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == 1 and g.info.field == h
+    if glass:
+        lat = oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), field=h)
+    else:
+        lat = oracle.Lat(W, H, 1.0, 0, field=h)
+    _check(capi, oracle, g, lat, ea, eb, ej, W * H, biases, 5, np.array([0.0, 0.2, 0.4407, 0.9, 2.5]))
+
+
+def test_field_scaled_coupling_and_per_replica_betas(capi, oracle, exact):
+    W, H, J, h = 256, 32, 0.37, 0.5                                   # antiferromagnetic |J| = 0.37, h <= 2|J|
+    ea, eb, ej = exact.square_lattice_edges(W, H, J)
+    g = capi.Graph(ea, eb, ej, biases=np.full(W * H, h))
+    assert g.info.fast_path == 1
+    lat = oracle.Lat(W, H, J, 1, field=h)
+    st = capi.States(g, SEEDS)
+    betas = [0.3, 1.1, 4.0]
+    st.set_betas(betas)
+    st.do_time_steps(6)
+    for r, s in enumerate(SEEDS):
+        ref = lat.init(s)
+        for t in range(6):
+            lat.sweep(ref, s, t, betas[r])
+        np.testing.assert_array_equal(st.packed()[r], ref)
+        assert st.energies()[r] == lat.energy_mag(ref)[0]
+    # a field beyond 2|J| (classes with fewer than two satisfied bonds would cost energy too) and site-dependent
+    # biases take the general path
+    assert capi.Graph(ea, eb, ej, biases=np.full(W * H, 0.75)).kind == capi.KIND_GENERAL
+    b = np.full(W * H, h); b[5] = 0.0
+    assert capi.Graph(ea, eb, ej, biases=b).kind == capi.KIND_GENERAL
+    assert capi.Graph(ea, eb, ej, biases=np.zeros(W * H)).info.fast_path == 0     # h = 0: the two-class kernels
+
+
+@pytest.mark.parametrize("W,H", [(256, 16), (512, 32)])
+@pytest.mark.parametrize("open_x,open_y", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("glass", [False, True])
+def test_open_boundaries_bit_exact(capi, oracle, exact, W, H, open_x, open_y, glass):
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(H) if glass else None, open_x, open_y)
+    perm = np.random.default_rng(1).permutation(int(keep.sum()))     # any edge order
+    a, b, j = ea[keep][perm], eb[keep][perm], ej[keep][perm]
+    r = capi.recognise_lattice2d(a, b, j, W * H)
+    assert r["is_lattice"] and r["open_x"] == open_x and r["open_y"] == open_y
+    g = capi.Graph(a, b, j, nvars=W * H)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == 2 and (bool(g.info.open_x), bool(g.info.open_y)) == (open_x, open_y)
+    if glass:
+        lat = oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), open_x=open_x, open_y=open_y)
+    else:
+        lat = oracle.Lat(W, H, 1.0, 0, open_x=open_x, open_y=open_y)
+    _check(capi, oracle, g, lat, a, b, j, W * H, None, 5, np.array([0.0, 0.3, 0.4407, 1.2, 3.0]))
+
+
+def test_open_lattice_with_a_field_or_a_missing_interior_bond_is_general(capi, exact):
+    W, H = 256, 16
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, None, True, False)
+    assert capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=np.full(W * H, 0.2)).kind == capi.KIND_GENERAL
+    k2 = keep.copy(); k2[np.flatnonzero(keep)[7]] = False             # one interior bond gone: not a lattice
+    assert not capi.recognise_lattice2d(ea[k2], eb[k2], ej[k2], W * H)["is_lattice"]
+    k3 = keep.copy(); k3[np.flatnonzero(~keep)[0]] = True             # one wrap-around bond present, the others not
+    assert not capi.recognise_lattice2d(ea[k3], eb[k3], ej[k3], W * H)["is_lattice"]
+
+
+def test_field_lattice_equilibrium_against_the_general_path(capi, exact):
+    """Independent check of the field kernel's physics: the thread-per-site CSR path (f64 local fields, other update order
+    within a colour class, other random numbers) samples the same Boltzmann distribution."""
+    W, H, h, beta, R = 256, 16, 0.3, 0.35, 48
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    biases = np.full(W * H, h)
+    obs = []
+    for force in (False, True):
+        g = capi.Graph(ea, eb, ej, biases=biases, force_general=force)
+        assert (g.kind == capi.KIND_GENERAL) == force
+        st = capi.States(g, capi.make_seeds(3 + force, R))
+        st.do_time_steps(300, beta)
+        e = st.do_time_steps(600, beta, per_step_energies=True).mean(axis=1)
+        obs.append((e, st.magnetisations().astype(np.float64)))
+    for a, b, name in ((obs[0][0], obs[1][0], "E"), (obs[0][1], obs[1][1], "M")):
+        z = (a.mean() - b.mean()) / math.sqrt(a.var(ddof=1) / R + b.var(ddof=1) / R)
+        assert abs(z) < 4.5, (name, z, a.mean(), b.mean())
+    assert obs[0][1].mean() > 0.3 * W * H                            # the field magnetises the paramagnet
+
+
+def test_python_api_keeps_field_and_open_lattices_on_the_fast_path(oracle, exact):
+    import py_monte_carlo as mod
+    W, H = 256, 16
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    lat = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=9)
+    lat.set_global_bias(0.25)                                         # lattice.rs:129-131
+    info = lat.engine_info()
+    assert info["kind"] == "lattice2d" and info["field"] == 0.25
+    e, s = lat.run_monte_carlo(0.4, 12, 3)
+    olat = oracle.Lat(W, H, 1.0, 0, field=0.25)
+    for r, seed in enumerate(lat.make_seeds(3)):
+        ref = olat.init(seed)
+        for t in range(12):
+            olat.sweep(ref, seed, t, 0.4)
+        assert np.array_equal(s[r], olat.unpack(ref).astype(bool)) and e[r] == olat.energy_mag(ref)[0]
+    es, ss = lat.run_monte_carlo_sampling(0.4, 6, 3, None, 2, 3)      # thermalisation 2, a sample every 3 steps
+    ea2, _ = lat.run_monte_carlo_annealing_and_get_energies([(0, 0.1), (8, 0.8)], 8, 3)
+    assert es.shape == (3, 2) and ss.shape == (3, 2, W * H) and ea2.shape == (3, 8)
+    lat.set_individual_bias(3, 1.0)                                   # site-dependent: general path
+    assert lat.engine_info()["kind"] == "general"
+    ci = mod.ClassicIsing(_edges(ea, eb, ej), 0.5, 2, 7)              # longitudinal field (classicising.rs:69)
+    ci.run_monte_carlo(0.3, 5)
+    olat = oracle.Lat(W, H, 1.0, 0, field=0.5)
+    for r, seed in enumerate(oracle.make_seeds(7, 2)):
+        ref = olat.init(seed)
+        for t in range(5):
+            olat.sweep(ref, seed, t, 0.3)
+        assert np.array_equal(ci.get_states()[r], olat.unpack(ref).astype(bool)) and ci.get_energies()[r] == olat.energy_mag(ref)[0]
+
+
+def test_tempering_on_a_field_lattice_uses_the_host_swap_step(capi, exact):
+    from helpers import OracleLatEngine  # noqa: F401  (the oracle engine of the plain lattice is not used here)
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering, HipEngine
+    W, H = 256, 16
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+
+    class FieldEngine(HipEngine):
+        def __init__(self):
+            self.graph = capi.Graph(ea, eb, ej, biases=np.full(W * H, 0.2))
+            self.nvars = self.graph.nvars
+            self.supports_on_stream_pt = self.graph.kind == capi.KIND_LATTICE2D and self.graph.info.fast_path == 0
+
+    pt = ClassicalTempering((ea, eb, ej), seed=5, engine_factory=FieldEngine)
+    for b in np.linspace(0.40, 0.44, 6):
+        pt.add_graph(float(b))
+    pt.timesteps(20, replica_swap_freq=2)
+    assert not pt._on_stream and pt.get_total_swaps() > 0 and sorted(pt.get_permutation()) == list(range(6))

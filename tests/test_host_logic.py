@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(capi):
     for name in sorted(declared):
         assert hasattr(L, name), f"libisingmc.so does not export {name}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert L.isingmc_abi_version() == 1
+    assert L.isingmc_abi_version() == 2
 
 
 def test_no_cpu_fallback(capi, exact):
@@ -108,8 +108,11 @@ def test_recogniser_rejects_non_lattices(capi, exact):
     ea3, eb3 = ea.copy(), eb.copy(); ea3[0], eb3[0] = ea3[2], eb3[2]
     assert not capi.recognise_lattice2d(ea3, eb3, ej, N)["is_lattice"]                       # duplicate bond
     assert not capi.recognise_lattice2d(ea, eb, ej, N + 1)["is_lattice"]                     # extra isolated site
-    open_mask = ~((ea % W == W - 1) & (eb % W == 0))                                          # open boundary in x
-    assert not capi.recognise_lattice2d(ea[open_mask], eb[open_mask], ej[open_mask], N)["is_lattice"]
+    open_mask = ~((ea % W == W - 1) & (eb % W == 0))                                          # open boundary in x: a lattice
+    r = capi.recognise_lattice2d(ea[open_mask], eb[open_mask], ej[open_mask], N)
+    assert r["is_lattice"] and r["open_x"] and not r["open_y"] and (r["width"], r["height"]) == (W, H)
+    half_open = open_mask.copy(); half_open[np.flatnonzero(~open_mask)[:3]] = True           # only some wrap-around bonds cut
+    assert not capi.recognise_lattice2d(ea[half_open], eb[half_open], ej[half_open], N)["is_lattice"]
     ea5, eb5, ej5 = exact.cubic_lattice_edges(4, -1.0)
     assert not capi.recognise_lattice2d(ea5, eb5, ej5, 64)["is_lattice"]
     with pytest.raises(ValueError, match="Must supply some edges"):

@@ -17,6 +17,15 @@ from pyisingmontecarlo_amd import _capi  # noqa: E402
 from pyisingmontecarlo_amd.tempering import ClassicalTempering  # noqa: E402
 
 
+def _pmc(name):
+    """HBM bytes per sweep launch from the committed counter passes (profiles/traffic_<name>.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"traffic_{name}.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def square(W, H, rng=None):
     ids = np.arange(W * H, dtype=np.uint64).reshape(H, W)
     ea = np.stack([ids, ids], axis=-1).reshape(-1)
@@ -43,9 +52,17 @@ def c4(steps):
     st.do_time_steps(10, 0.1)
     ms = st.do_time_steps_timed(steps, betas)
     e = st.energies().mean() / L ** 2
-    return {"config": "c4", "lattice": [L, L], "replicas": R, "steps": steps, "attempts_per_s": R * L * L * steps / (ms * 1e-3),
-            "ms_per_step": ms / steps, "bytes_per_attempt": 0.875,
-            "hbm_frac": R * L * L * steps / (ms * 1e-3) * 0.875 / 8e12, "final_energy_per_site": e}
+    rate = R * L * L * steps / (ms * 1e-3)
+    out = {"config": "c4", "lattice": [L, L], "replicas": R, "steps": steps, "attempts_per_s": rate,
+           "ms_per_step": ms / steps, "bytes_per_attempt": 0.875,
+           "hbm_frac_algorithmic": rate * 0.875 / 8e12, "final_energy_per_site": e,
+           "note": "0.875 B/attempt counts the 0.5 B of coupling-sign planes per replica; they are shared by all replicas and "
+                   "stay in L2, so the HBM traffic is near 0.375 B/attempt: see hbm_frac_counters"}
+    pmc = _pmc("c4")                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script (profiles/)
+    if pmc:
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L * L / 2)
+        out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
+    return out
 
 
 def c3(steps):
@@ -75,9 +92,20 @@ def c5(steps):
     st.do_time_steps(2, 0.2217)
     ms = st.do_time_steps_timed(steps, 0.2217)
     rate = R * L ** 3 * steps / (ms * 1e-3)
-    return {"config": "c5", "lattice": [L, L, L], "replicas": R, "steps": steps, "n_colours": int(g.info.n_colours),
-            "attempts_per_s": rate, "ms_per_step": ms / steps, "bytes_per_attempt": 48.375,
-            "hbm_frac": rate * 48.375 / 8e12, "graph_build_s": ingest, "energy_per_site": st.energies().mean() / L ** 3}
+    # the replica-packed path's OWN algorithmic bytes: per position and group of 32 replicas a class launch reads its word
+    # (4 B), writes it (4 B), reads every word of the other class once (4 B) and 6 block headers per 64 positions (0.75 B)
+    bpa = (4 + 4 + 4 + 0.75) / 32
+    out = {"config": "c5", "lattice": [L, L, L], "replicas": R, "steps": steps, "n_colours": int(g.info.n_colours),
+           "attempts_per_s": rate, "ms_per_step": ms / steps, "bytes_per_attempt": bpa, "hbm_frac": rate * bpa / 8e12,
+           "csr_bytes_per_attempt": 48.375, "vs_per_replica_csr_ceiling": rate / (8e12 / 48.375),
+           "graph_build_s": ingest, "energy_per_site": st.energies().mean() / L ** 3,
+           "note": "hbm_frac uses the packed path's own bytes; SURVEY 8d's 48.375 B/attempt is the per-replica CSR stream this "
+                   "path avoids (32 replicas share every index): vs_per_replica_csr_ceiling is the speed-up over THAT roofline"}
+    pmc = _pmc("c5")
+    if pmc:
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L ** 3 / 2)
+        out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
+    return out
 
 
 if __name__ == "__main__":
