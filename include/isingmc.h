@@ -194,6 +194,9 @@ int isingmc_pt_attach(isingmc_states *states, const double *ladder_betas, size_t
 int isingmc_pt_buffers(isingmc_states *states, void **d_local_out, void **d_all_out, size_t *per_rank_out);
 int isingmc_pt_time_steps(isingmc_states *states, size_t timesteps); /* enqueue only */
 int isingmc_pt_measure(isingmc_states *states);                      /* enqueue only */
+/* single rank: `timesteps` sweeps with an exchange round after every swap_every-th one, enqueued in one call (on
+ * mid-size lattices one persistent launch whose strips exchange temperatures themselves; same decisions) */
+int isingmc_pt_run(isingmc_states *states, size_t timesteps, size_t swap_every);
 int isingmc_pt_swap(isingmc_states *states);                         /* enqueue only */
 /* synchronises; perm_out = uint32[n_rungs] (rung -> slot), exchange rounds done, accepted swaps */
 int isingmc_pt_state(isingmc_states *states, uint32_t *perm_out, uint64_t *round_out, uint64_t *swaps_out);

@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "isingmc_pt_time_steps": (C.c_int, [_vp, C.c_size_t]),
     "isingmc_pt_measure": (C.c_int, [_vp]),
+    "isingmc_pt_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t]),
     "isingmc_pt_swap": (C.c_int, [_vp]),
     "isingmc_pt_state": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "isingmc_states_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
@@ -339,6 +340,9 @@ class States:
 
     def pt_time_steps(self, timesteps):
         _check(lib().isingmc_pt_time_steps(self._h, timesteps))
+
+    def pt_run(self, timesteps, swap_every):
+        _check(lib().isingmc_pt_run(self._h, timesteps, swap_every))
 
     def pt_measure(self):
         _check(lib().isingmc_pt_measure(self._h))

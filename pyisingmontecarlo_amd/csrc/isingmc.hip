@@ -125,6 +125,8 @@ struct isingmc_states {
     size_t halo_cap = 0; // granules allocated
     uint32_t *d_strip_err = nullptr;
     uint32_t strip_epoch = 0;
+    unsigned long long *d_pt_mail = nullptr, *d_pt_round_counts = nullptr; // in-kernel exchange rounds (StripLadder)
+    uint32_t *d_pt_perm2 = nullptr;
     unsigned long long *d_strip_fin = nullptr; // [cap] final-measurement counters of the strip kernel (zero between launches)
     bool meas_fresh = false; // the tempering send buffer holds the energies of the CURRENT configurations (written by the last strip launch)
     // sampling pipeline (isingmc_run_sampling): two slabs of samples in flight
@@ -166,6 +168,8 @@ struct isingmc_states {
         if (d_halo) (void)hipFree(d_halo);
         if (d_strip_err) (void)hipFree(d_strip_err);
         if (d_strip_fin) (void)hipFree(d_strip_fin);
+        for (void *p : {(void *)d_pt_mail, (void *)d_pt_round_counts, (void *)d_pt_perm2})
+            if (p) (void)hipFree(p);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
                         (void *)d_pt_counters})
             if (p) (void)hipFree(p);
@@ -1370,7 +1374,7 @@ static hipEvent_t g_strip_done[64] = {};
 
 // one pass: replicas [r0, r0 + n) for timesteps [s->t, s->t + nk).  steps_out / final_out: see lat_strip_kernel
 static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t n, size_t nk, const LatThr *d_thr_steps,
-                        uint32_t thr_stride, unsigned long long *steps_out, double *final_energies)
+                        uint32_t thr_stride, unsigned long long *steps_out, double *final_energies, const StripLadder *ladder = nullptr)
 {
     const isingmc_graph *g = s->g;
     const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
@@ -1410,8 +1414,8 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
         else HIP_TRY(hipStreamWaitEvent(s->stream, ev, 0));
         HIP_TRY(strip_launch(!g->uniform_sign, P.nw, unsigned(n * a.n_strips), lds, s->stream, s->d_state + r0 * g->state_words, g->geom, a, s->t,
                              uint32_t(nk), s->d_keys + r0, d_thr_steps, thr_stride, s->has_betas ? s->d_thr + r0 : nullptr, g->d_jneg,
-                             g->jneg_uniform, s->d_halo + r0 * size_t(a.n_strips) * 4 * g->geom.wpr, steps_out, fin, uint32_t(s->R),
-                             s->d_strip_err));
+                             g->jneg_uniform, s->d_halo + r0 * size_t(a.n_strips) * 4 * g->geom.wpr, steps_out, fin,
+                             ladder ? *ladder : StripLadder{}, uint32_t(s->R), s->d_strip_err));
         HIP_TRY(hipEventRecord(ev, s->stream));
     }
     return ISINGMC_OK;
@@ -1964,6 +1968,57 @@ extern "C" int isingmc_pt_time_steps(isingmc_states *s, size_t timesteps)
     // the strip kernel measures the final configurations itself: isingmc_pt_measure then needs no pass over the planes
     return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false,
                      /*final_energies=*/s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
+}
+
+// The loop of tempering.rs:177-194 { timesteps(swap_every); parallel_tempering_step } for `timesteps` sweeps in ONE library
+// call (enqueue only), with an exchange round after every swap_every-th sweep.  Single rank + strip geometry: one persistent
+// launch whose strips exchange temperatures pair by pair through rung-indexed mailboxes (StripLadder), only the last
+// round at a kernel boundary; otherwise the per-round sequence of the calls above.  Ranks > 1 must interleave their
+// all-gather and therefore keep calling isingmc_pt_time_steps / _measure / _swap themselves.
+extern "C" int isingmc_pt_run(isingmc_states *s, size_t timesteps, size_t swap_every)
+{
+    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
+    if (swap_every == 0) return fail(ISINGMC_ERR_INVALID, "swap_every must be positive");
+    if (s->pt_world != 1) return fail(ISINGMC_ERR_INVALID, "isingmc_pt_run is for a single rank: the all-gather of a sharded ladder sits between measure and swap");
+    TRY(use_device(s->g->device));
+    const isingmc_graph *g = s->g;
+    const size_t rounds = timesteps / swap_every, tail = timesteps % swap_every;
+    const StripPlan P = s->R ? strip_plan(s, rounds * swap_every) : StripPlan{};
+    const bool in_kernel = P.use && P.replicas_per_pass >= s->R && rounds >= 2 && rounds * swap_every <= 65536 &&
+                           s->R == s->pt.n_rungs && env_int("ISINGMC_PT_IN_KERNEL", 1) != 0;
+    if (in_kernel) {
+        const size_t R = s->R, nk = rounds * swap_every;
+        if (!s->d_pt_mail) {
+            TRY(dev_alloc(&s->d_pt_mail, 4 * R));
+            TRY(dev_alloc(&s->d_pt_round_counts, 2 * R));
+            TRY(dev_alloc(&s->d_pt_perm2, R));
+            HIP_TRY(hipMemsetAsync(s->d_pt_mail, 0, 4 * R * sizeof(unsigned long long), s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_pt_round_counts, 0, 2 * R * sizeof(unsigned long long), s->stream));
+        }
+        // the number of the first round is on the device (exchange rounds never synchronise with the host): read it once here
+        unsigned long long c[2];
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
+        const StripLadder lad{s->d_pt_ladder, reinterpret_cast<const unsigned long long *>(s->d_pt_ladder_thr), s->d_pt_perm, s->d_pt_perm2,
+                              s->d_pt_mail, s->d_pt_round_counts, s->d_pt_counters, c[0], uint32_t(R), uint32_t(swap_every), s->pt.seed_lo,
+                              s->pt.seed_hi, g->jabs, 2ll * (long long)g->nvars};
+        s->meas_fresh = false;
+        TRY(launch_strip(s, P, 0, R, nk, nullptr, 0, nullptr, s->d_pt_all + s->pt.slot_offset, &lad));
+        s->strip_epoch += uint32_t(2 * nk);
+        s->t += nk;
+        s->meas_fresh = true; // the launch wrote the final energies
+        HIP_TRY(hipMemcpyAsync(s->d_pt_perm, s->d_pt_perm2, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+        TRY(isingmc_pt_measure(s));
+        TRY(isingmc_pt_swap(s)); // the last round of the block, at the kernel boundary (it also relabels d_thr / d_beta)
+    } else {
+        for (size_t k = 0; k < rounds; k++) {
+            TRY(isingmc_pt_time_steps(s, swap_every));
+            TRY(isingmc_pt_measure(s));
+            TRY(isingmc_pt_swap(s));
+        }
+    }
+    if (tail) TRY(isingmc_pt_time_steps(s, tail));
+    return ISINGMC_OK;
 }
 
 // enqueue: energies of the local slots -> the local send buffer (and straight into the gathered

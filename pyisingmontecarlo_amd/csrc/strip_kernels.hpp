@@ -29,6 +29,54 @@
 
 namespace isingmc {
 
+// exp(x) for x <= 0 with IEEE f64 ops + fma only: the device twin of det_exp (general_kernels.hpp) / orc_det_exp
+__device__ __forceinline__ double strip_det_exp(double x)
+{
+    if (x >= 0.0) return 1.0;
+    if (x < -40.0) return 0.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double kf = floor(fma(x, LOG2E, 0.5));
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long k = (long long)kf; // in [-58, 0]
+    return p * __longlong_as_double((1023ll + k) << 52);
+}
+
+// bounded wait for a granule {tag, value}: false on a timeout (or when another workgroup has raised *err)
+__device__ __forceinline__ bool strip_wait_granule(const unsigned long long *p, const uint32_t want, uint32_t &value, uint32_t *err)
+{
+    const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+    uint32_t spins = 0;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load((strip_gu64)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (uint32_t(v >> 32) == want) {
+            value = uint32_t(v);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0 && (__builtin_amdgcn_s_memrealtime() - start > STRIP_TIMEOUT_TICKS ||
+                                     __hip_atomic_load((strip_gu32)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicOr(err, STRIP_ERR_TIMEOUT);
+            return false;
+        }
+    }
+}
+
 // granules of one replica: [strip][plane][side: 0 = its top row, 1 = its bottom row][wpr]
 __device__ __forceinline__ size_t strip_granule(const LatGeom &g, uint32_t strip, uint32_t plane, uint32_t side)
 {
@@ -77,12 +125,13 @@ __device__ __forceinline__ void strip_update_quad(uint32_t *lds, const uint32_t 
 // thr_steps / thr_stride / thr_replica: as lat_resident_kernel.  steps_out (optional): satisfied bonds / up spins
 // after every timestep, [step][replica][2], zeroed by the host (the strips of a replica add into it).
 // fin (optional): energies of the final configurations, see StripFinal.
-template <bool PMJ, int NW>
+// LAD: exchange rounds inside the launch (StripLadder); a separate instantiation, so that launches without them pay nothing
+template <bool PMJ, int NW, bool LAD>
 __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const StripArgs a, const uint64_t t0, const uint32_t timesteps,
     const uint2 *__restrict__ keys, const LatThr *__restrict__ thr_steps, const uint32_t thr_stride,
     const LatThr *__restrict__ thr_replica, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
-    unsigned long long *__restrict__ halo, unsigned long long *__restrict__ steps_out, const StripFinal fin,
+    unsigned long long *__restrict__ halo, unsigned long long *__restrict__ steps_out, const StripFinal fin, const StripLadder lad,
     const uint32_t n_replicas, uint32_t *__restrict__ err)
 {
     constexpr uint32_t NT = 64 * NW;
@@ -115,6 +164,16 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
         lds[p * PL + (side ? (S + 1) * wpr : 0) + w] = mine[size_t(p) * g.wpp + size_t(side ? y_dn : y_up) * wpr + w];
     }
     if (NW > 1 && tid == 0) red[8] = 0;
+    // in-kernel tempering: the rung this replica holds (the inverse of perm), found by the workgroup's threads
+    uint32_t my_rung = 0;
+    if constexpr (LAD) {
+        if (tid == 0) red[9] = 0;
+        if constexpr (NW > 1) __syncthreads();
+        for (uint32_t i = tid; i < lad.n_rungs; i += NT)
+            if (lad.perm_in[i] == r) red[9] = i; // exactly one hit (perm is a permutation of the slots; single shard: slot = replica)
+        if constexpr (NW > 1) __syncthreads();
+        my_rung = __builtin_amdgcn_readfirstlane(red[9]);
+    }
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
 
@@ -142,10 +201,13 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
 #endif
 
     for (uint32_t k = 0; k < timesteps; k++) {
-        const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
+        LatThr thr;
+        if constexpr (LAD) thr = LatThr{lad.ladder_thr[2 * size_t(my_rung)], lad.ladder_thr[2 * size_t(my_rung) + 1]};
+        else thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
         uint32_t sat = 0, up = 0;
         const bool last_step = k + 1 == timesteps;
-        const bool measure = (steps_out != nullptr) || (fin.counts != nullptr && last_step);
+        const bool exchange = LAD && !last_step && (k + 1) % lad.swap_every == 0; // an exchange round follows this timestep
+        const bool measure = (steps_out != nullptr) || (fin.counts != nullptr && last_step) || exchange;
 #pragma unroll 1
         for (uint32_t colour = 0; colour < 2; colour++) {
             const uint32_t j = 2 * k + colour; // half-sweep index of this launch
@@ -204,7 +266,9 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
                 }
             }
 #ifndef ISINGMC_STRIP_NO_PRECOMPUTE
-            if (j + 1 < 2 * timesteps) quad_random(R, Q, 1 - colour, t0 + k + colour, key, vk); // the next half-sweep's words
+            // the next half-sweep's words; in front of an exchange round they are drawn AFTER the replica's count has been
+            // posted (the other strips and the partner replica wait for that post) and before the wait for the mailboxes
+            if (j + 1 < 2 * timesteps && !(exchange && colour == 1)) quad_random(R, Q, 1 - colour, t0 + k + colour, key, vk);
 #endif
         }
         if (measure) { // get_energy after this timestep (lattice.rs:454): the strips of a replica add up
@@ -226,6 +290,18 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
                     atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2, s4);
                     atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2 + 1, u4);
                 }
+                if (exchange) { // the replica's total for this round: the last strip to arrive posts it at the replica's rung
+                    const unsigned long long round = lad.round0 + (k + 1) / lad.swap_every - 1;
+                    unsigned long long *cnt = lad.round_counts + size_t(round & 1) * n_replicas + r;
+                    const unsigned long long mine_add = s4 | (1ull << STRIP_ARRIVAL_SHIFT);
+                    const unsigned long long old = atomicAdd(cnt, mine_add);
+                    if ((old >> STRIP_ARRIVAL_SHIFT) + 1 == a.n_strips) {
+                        const unsigned long long total = (old + mine_add) & ((1ull << STRIP_ARRIVAL_SHIFT) - 1);
+                        __hip_atomic_store((strip_gu64)cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // before the post: nobody adds again until it has seen the post
+                        __hip_atomic_store((strip_gu64)(lad.mail + size_t(round & 3) * lad.n_rungs + my_rung),
+                                           ((unsigned long long)(uint32_t(round) + 1u) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (fin.counts && last_step) {
                     // ONE atomic carries the count and the arrival: whoever sees n_strips - 1 earlier arrivals holds the total
                     const unsigned long long mine_add = s4 | (1ull << STRIP_ARRIVAL_SHIFT);
@@ -238,6 +314,59 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
                 }
             }
         }
+        if (exchange) { // ---- one exchange round, decided by every strip of both partners alike (host twin: pt_swap_round)
+#ifndef ISINGMC_STRIP_NO_PRECOMPUTE
+            quad_random(R, Q, 0, t0 + k + 1, key, vk);
+#endif
+            const unsigned long long round = lad.round0 + (k + 1) / lad.swap_every - 1;
+            const uint32_t parity = uint32_t(round & 1), want = uint32_t(round) + 1u;
+            const unsigned long long *box = lad.mail + size_t(round & 3) * lad.n_rungs;
+            uint32_t partner = 0xFFFFFFFFu; // pairs (i, i + 1) with i of the round's parity
+            if ((my_rung & 1u) == parity) { if (my_rung + 1 < lad.n_rungs) partner = my_rung + 1; }
+            else if (my_rung >= 1) partner = my_rung - 1;
+            uint32_t new_rung = my_rung;
+            bool bail = false;
+            // lanes 0 and 1 wait for the two mailboxes side by side (the own one is also the round's barrier of this replica's strips)
+            uint32_t got = 0;
+            if (tid == 0) bail = !strip_wait_granule(box + my_rung, want, got, err);
+            if (tid == 1 && partner != 0xFFFFFFFFu) bail = !strip_wait_granule(box + partner, want, got, err);
+            const uint32_t sat_mine = __shfl(got, 0), sat_other = __shfl(got, 1);
+            bail = __any(bail) != 0; // (wave 0; the other waves learn it through red[8])
+            if (tid == 0) {
+                if (!bail && partner != 0xFFFFFFFFu) {
+                    const uint32_t lo = my_rung < partner ? my_rung : partner;
+                    const double e_mine = lad.jabs * double(lad.n_bonds - 2 * (long long)sat_mine);
+                    const double e_other = lad.jabs * double(lad.n_bonds - 2 * (long long)sat_other);
+                    const double e_lo = my_rung < partner ? e_mine : e_other, e_hi = my_rung < partner ? e_other : e_mine;
+                    const double d = (lad.ladder[lo] - lad.ladder[lo + 1]) * (e_lo - e_hi);
+                    bool accept = d >= 0.0;
+                    if (!accept) {
+                        const uint4 rnd = philox4x32_10(make_uint4(lo, uint32_t(round), uint32_t(round >> 32), 0x50545357u),
+                                                        make_uint2(lad.seed_lo, lad.seed_hi));
+                        const unsigned long long x = ((unsigned long long)rnd.y << 32) | rnd.x;
+                        accept = double(x >> 11) * (1.0 / 9007199254740992.0) < strip_det_exp(d);
+                    }
+                    if (accept) {
+                        new_rung = partner;
+                        if (strip == 0 && my_rung < partner) atomicAdd(lad.counters + 1, 1ull); // once per accepted pair
+                    }
+                }
+            }
+            if constexpr (NW > 1) {
+                if (tid == 0) { red[9] = new_rung; if (bail) red[8] = 1; }
+                __syncthreads();
+                if (red[8]) return;
+                my_rung = __builtin_amdgcn_readfirstlane(red[9]);
+                __syncthreads(); // red[9] is free again
+            } else {
+                if (__builtin_amdgcn_readfirstlane(uint32_t(bail))) return;
+                my_rung = __builtin_amdgcn_readfirstlane(new_rung);
+            }
+        }
+    }
+    if (LAD && strip == 0 && tid == 0) { // the ladder as this launch leaves it
+        lad.perm_out[my_rung] = r;
+        if (r == 0) lad.counters[0] = lad.round0 + (timesteps - 1) / lad.swap_every;
     }
     if constexpr (NW > 1) __syncthreads();
 #pragma unroll

@@ -35,11 +35,31 @@ struct StripFinal {
     long long n_bonds;
 };
 
+// Parallel-tempering exchange rounds INSIDE the launch (single GPU): after every swap_every-th timestep except the last of
+// the launch, the replicas at neighbouring rungs exchange temperatures exactly as pt_swap_kernel / isingmc_host_pt_swap_round
+// decide it (same Philox counters (rung, round), same det_exp) -- but pair by pair, with no kernel boundary: the strip of a
+// replica that arrives last posts the replica's satisfied-bond total into a mailbox indexed by the replica's RUNG
+// (an 8-byte {tag = round + 1, count} granule, as the halo rows), every strip of the two partners polls both mailboxes,
+// takes the same decision and relabels itself.  ladder == nullptr: off.
+struct StripLadder {
+    const double *ladder;                  // beta per rung
+    const unsigned long long *ladder_thr;  // {T3, T4} per rung
+    const uint32_t *perm_in;               // rung -> slot at launch (not written during the launch)
+    uint32_t *perm_out;                    // rung -> slot after the launch's rounds (a different buffer)
+    unsigned long long *mail;              // [4][n_rungs] granules, zero before the first use, tags grow with the round
+    unsigned long long *round_counts;      // [2][n_replicas]: satisfied bonds | arrived strips << 48 of the round's parity, zero between rounds
+    unsigned long long *counters;          // [0] = exchange rounds done (set to round0 + rounds of this launch at its end), [1] += accepted swaps
+    unsigned long long round0;             // number of the launch's first round
+    uint32_t n_rungs, swap_every, seed_lo, seed_hi;
+    double jabs;
+    long long n_bonds;
+};
+
 // one launch: `blocks` strips of `nw` waves (1 or 4) each; arguments as lat_strip_kernel
 hipError_t strip_launch(bool pmj, int nw, unsigned blocks, size_t lds_bytes, hipStream_t stream, uint32_t *state, const LatGeom &g,
                         const StripArgs &a, uint64_t t0, uint32_t timesteps, const uint2 *keys, const LatThr *thr_steps,
                         uint32_t thr_stride, const LatThr *thr_replica, const uint32_t *jneg, uint32_t jneg_uniform,
-                        unsigned long long *halo, unsigned long long *steps_out, const StripFinal &fin, uint32_t n_replicas,
-                        uint32_t *err);
+                        unsigned long long *halo, unsigned long long *steps_out, const StripFinal &fin, const StripLadder &lad,
+                        uint32_t n_replicas, uint32_t *err);
 
 } // namespace isingmc

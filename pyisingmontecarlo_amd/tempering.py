@@ -175,6 +175,11 @@ class ClassicalTempering:
             if self._hi > self._lo:
                 self._states.do_time_steps(t)
             return
+        if self._on_stream and self._world == 1 and self._hi > self._lo:
+            # single rank: the whole loop is one library call (one persistent launch on mid-size lattices)
+            self._states.pt_run(int(t), int(replica_swap_freq))
+            self._states.synchronize()
+            return
         done = 0
         while done < t:
             b = min(int(replica_swap_freq), t - done)

@@ -98,14 +98,19 @@ def test_on_stream_tempering_on_the_strip_path(capi, exact, monkeypatch):
     W, H, G = 1024, 256, 12
     edges = exact.square_lattice_edges(W, H, -1.0)
     runs = []
-    for mode in ("1", "0"):
+    # strip kernel with the exchange rounds inside the launch (rung-indexed mailboxes) / strip kernel, one launch per round /
+    # per-colour launches + lat_measure_kernel
+    for mode, in_kernel in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("ISINGMC_STRIP", mode)
+        monkeypatch.setenv("ISINGMC_PT_IN_KERNEL", in_kernel)
         pt = ClassicalTempering(edges, seed=31)
         for b in np.linspace(0.4400, 0.4402, G):            # 262 144 spins: neighbouring rungs must be this close to exchange
             pt.add_graph(float(b))
         pt.timesteps(4)
-        pt.timesteps(40, replica_swap_freq=4)                      # 10 exchange rounds on the stream
+        pt.timesteps(43, replica_swap_freq=4)                      # 10 exchange rounds on the stream + 3 sweeps
+        pt.timesteps(9, replica_swap_freq=3)                       # the round counter continues (odd / even pairing)
         runs.append((pt.get_permutation(), pt.get_total_swaps(), pt._states.packed(), pt._states.energies()))
-    assert runs[0][1] == runs[1][1] > 0
-    for a, b in zip(runs[0], runs[1]):
-        np.testing.assert_array_equal(a, b)
+    assert runs[0][1] == runs[1][1] == runs[2][1] > 0
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)

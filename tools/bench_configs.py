@@ -72,6 +72,7 @@ def c3(steps):
     for b in 0.1 + 0.9 * np.arange(G) / 511 * 8:      # every 8th rung of the 512-ladder: same span on one GPU
         pt.add_graph(float(b))
     pt.timesteps(20)
+    pt.timesteps(40, replica_swap_freq=10)              # warm-up of the exchange path (its buffers are created on first use)
     t0 = time.perf_counter()
     n_blocks = steps // 10
     pt.timesteps(n_blocks * 10, replica_swap_freq=10)   # sweeps + exchange rounds, all on the engine's stream
@@ -113,5 +114,5 @@ if __name__ == "__main__":
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     for name in args or ["c3", "c4", "c5"]:
         fn = {"c3": c3, "c4": c4, "c5": c5}[name]
-        default = {"c3": 200, "c4": 200, "c5": 20}[name]
+        default = {"c3": 1000, "c4": 200, "c5": 20}[name]
         print(json.dumps(fn(steps or default)), flush=True)
