@@ -107,3 +107,24 @@ def test_from_arrays_extension(mod):
     assert lat.make_seeds(2) == mod.Lattice(EDGES, 3).make_seeds(2)
     with pytest.raises(ValueError):
         mod.Lattice.from_arrays(np.array([0]), np.array([1, 2]), np.array([1.0]))
+
+
+def test_device_list_of_the_in_process_fan_out(mod, monkeypatch):
+    """ISINGMC_DEVICES / set_devices (extension): the device list Lattice.run_monte_carlo* fans its experiments out over.
+    Host-side parsing only -- no device is touched before the first run."""
+    edges = [((0, 1), 1.0), ((1, 2), -1.0)]
+    monkeypatch.delenv("ISINGMC_DEVICES", raising=False)
+    monkeypatch.delenv("ISINGMC_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert mod.Lattice(edges).get_devices() == [0]
+    monkeypatch.setenv("ISINGMC_DEVICE", "3")
+    assert mod.Lattice(edges).get_devices() == [3]
+    monkeypatch.setenv("ISINGMC_DEVICES", "0, 2,2,5")
+    lat = mod.Lattice(edges)
+    assert lat.get_devices() == [0, 2, 2, 5]                       # the list wins over ISINGMC_DEVICE; an ordinal may repeat
+    lat.set_device(1)
+    assert lat.get_devices() == [1]
+    lat.set_devices([4, 4])
+    assert lat.clone().get_devices() == [4, 4]
+    with pytest.raises(ValueError):
+        lat.set_devices([])

@@ -1,6 +1,8 @@
 """Randomised parity (hypothesis, derandomised): random graphs / lattices / parameters on the GPU against
 the oracle engines, bit for bit.  Covers ragged inputs the hand-written cases miss: duplicate edges, self
 loops, isolated sites, odd replica counts, zero-length runs, extreme betas."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -97,3 +99,68 @@ def test_random_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, seed)
         for t in range(T):
             lat.sweep(ref, seeds[r], t, beta)
         assert np.array_equal(packed[r], ref)
+
+
+@settings(max_examples=25, **COMMON)
+@given(wq=st.sampled_from([4, 8, 16, 32]), rows=st.sampled_from([2, 4, 6, 16]), pm=st.booleans(), R=st.integers(1, 9),
+       T=st.integers(2, 6), beta=st.sampled_from([0.0, 0.3, 0.4407, 1.5]), nw=st.sampled_from(["1", "4"]),
+       per_step=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
+def test_random_strip_lattices(capi, oracle, exact, wq, rows, pm, R, T, beta, nw, per_step, seed):
+    """The persistent strip kernel on random geometries: W = 256 .. 2048, H = a few strips, 1 or 4 waves per strip."""
+    W = 64 * wq
+    S = 64 * int(nw) // (wq // 4)                    # rows per strip
+    H = S * (rows if rows * S >= 4 else 4)
+    if H % 2 or H < 4:
+        H *= 2
+    os.environ["ISINGMC_STRIP"], os.environ["ISINGMC_STRIP_NW"], os.environ["ISINGMC_DISABLE_RESIDENT"] = "1", nw, "1"
+    try:
+        ea, eb, ej = exact.square_lattice_edges(W, H, 1.0 if pm else -1.0, np.random.default_rng(seed % 2 ** 32) if pm else None)
+        graph = capi.Graph(ea, eb, ej)
+        seeds = capi.make_seeds(seed, R)
+        states = capi.States(graph, seeds)
+        eps = states.do_time_steps(T, beta, per_step_energies=per_step)
+        lat = (oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8)) if pm
+               else oracle.Lat(W, H, 1.0, 0))
+        packed = states.packed()
+        for r in sorted({0, R - 1}):
+            ref = lat.init(seeds[r])
+            for t in range(T):
+                lat.sweep(ref, seeds[r], t, beta)
+                if per_step:
+                    assert eps[r, t] == lat.energy_mag(ref)[0]
+            assert np.array_equal(packed[r], ref)
+    finally:
+        for k in ("ISINGMC_STRIP", "ISINGMC_STRIP_NW", "ISINGMC_DISABLE_RESIDENT"):
+            os.environ.pop(k, None)
+
+
+@settings(max_examples=25, **COMMON)
+@given(wq=st.sampled_from([4, 8, 12]), H=st.sampled_from([4, 6, 16, 34]), pm=st.booleans(), R=st.integers(1, 4), T=st.integers(0, 5),
+       beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0, -0.3]), jabs=st.sampled_from([1.0, 0.3]),
+       mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy"]), seed=st.integers(0, 2 ** 64 - 1))
+def test_random_field_and_open_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, mode, seed):
+    """Multi-class checkerboard kernels on random geometries, couplings, fields and boundary conditions."""
+    W = 64 * wq
+    ea, eb, ej = exact.square_lattice_edges(W, H, jabs if pm else -jabs, np.random.default_rng(seed % 2 ** 32) if pm else None)
+    h = {"field+": 0.37 * jabs, "field-": -1.3 * jabs, "field_max": 2.0 * jabs}.get(mode, 0.0)
+    ox, oy = mode in ("open_x", "open_xy"), mode in ("open_y", "open_xy")
+    keep = np.ones(len(ea), dtype=bool)
+    if ox:
+        keep &= ~((ea % W == W - 1) & (eb % W == 0))
+    if oy:
+        keep &= ~((ea // W == H - 1) & (eb // W == 0))
+    graph = capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=np.full(W * H, h) if h else None)
+    assert graph.kind == capi.KIND_LATTICE2D and graph.info.fast_path == (1 if h else 2)
+    kw = dict(field=h, open_x=ox, open_y=oy)
+    lat = (oracle.Lat(W, H, jabs, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), **kw) if pm
+           else oracle.Lat(W, H, jabs, 0, **kw))
+    seeds = capi.make_seeds(seed, R)
+    states = capi.States(graph, seeds)
+    states.do_time_steps(T, beta)
+    packed, energies = states.packed(), states.energies()
+    for r in range(R):
+        ref = lat.init(seeds[r])
+        for t in range(T):
+            lat.sweep(ref, seeds[r], t, beta)
+        assert np.array_equal(packed[r], ref)
+        assert energies[r] == lat.energy_mag(ref)[0]
