@@ -1678,6 +1678,9 @@ extern "C" int isingmc_get_packed_states(isingmc_states *s, uint32_t *words_out)
     return ISINGMC_OK;
 }
 
+static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies);
+static void madvise_hugepages(void *p, size_t bytes);
+
 extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes)
 {
     if (!s || !states_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
@@ -1685,17 +1688,29 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
     TRY(use_device(s->g->device));
     const isingmc_graph *g = s->g;
     if (s->packed) return s->R ? pk_get_states(s, states_out, replica_stride_bytes, nullptr) : ISINGMC_OK;
-    // packed device words -> host, in slabs of replicas, unpacked to bytes by host threads
-    const size_t slab = std::max<size_t>(1, std::min<size_t>(s->R, (size_t(256) << 20) / (g->state_words * 4)));
-    std::vector<uint32_t> words(slab * g->state_words);
-    for (size_t r0 = 0; r0 < s->R; r0 += slab) {
-        const size_t n = std::min(slab, s->R - r0);
-        HIP_TRY(hipMemcpyAsync(words.data(), s->d_state + r0 * g->state_words, n * g->state_words * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        parallel_for(n, [&](size_t i) {
-            unpack_state(g, words.data() + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes);
-        });
+    // packed device words -> pinned host memory in slabs of replicas (<= 64 MiB), two in flight on the copy stream, expanded
+    // to bytes by the host threads while the next slab crosses PCIe (the buffers of the sampling pipeline)
+    if (s->R == 0) return ISINGMC_OK;
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(s->R, (size_t(64) << 20) / (g->state_words * 4)));
+    const size_t n_slabs = (s->R + slab - 1) / slab;
+    TRY(sampling_reserve(s, slab * g->state_words, 0, 0));
+    madvise_hugepages(states_out, s->R * replica_stride_bytes);
+    HIP_TRY(hipEventRecord(s->sample_ready[0], s->stream)); // everything queued on the engine's stream comes first
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->sample_ready[0], 0));
+    const auto copy_slab = [&](size_t j) {
+        const size_t r0 = j * slab, n = std::min(slab, s->R - r0);
+        HIP_TRY(hipMemcpyAsync(s->h_samples[j & 1], s->d_state + r0 * g->state_words, n * g->state_words * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_TRY(hipEventRecord(s->sample_copied[j & 1], s->copy_stream));
+        return int(ISINGMC_OK);
+    };
+    TRY(copy_slab(0));
+    for (size_t j = 0; j < n_slabs; j++) {
+        HIP_TRY(hipEventSynchronize(s->sample_copied[j & 1]));
+        if (j + 1 < n_slabs) TRY(copy_slab(j + 1)); // into the other buffer, which slab j-1's expansion has released
+        const size_t r0 = j * slab, n = std::min(slab, s->R - r0);
+        const uint32_t *words = s->h_samples[j & 1];
+        parallel_for(n, [&](size_t i) { unpack_state(g, words + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes); });
     }
     return ISINGMC_OK;
 }
