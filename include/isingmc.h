@@ -61,9 +61,11 @@ typedef struct {
     uint32_t n_colours;  /* independent sets per timestep (2 on the lattice path) */
     uint64_t state_words;/* 32-bit words of packed spin state per replica */
     int32_t fast_path;   /* LATTICE2D: 0 = periodic, no field; 1 = uniform field (set_global_bias, lattice.rs:129-131;
-                            ClassicIsing longitudinal, classicising.rs:69); 2 = open boundaries */
+                            ClassicIsing longitudinal, classicising.rs:69); 2 = open boundaries;
+                            3 = anisotropic (|J| of the horizontal bonds != |J| of the vertical ones) */
     int32_t open_x, open_y; /* LATTICE2D: no bonds between columns W-1 and 0 / rows H-1 and 0 */
     double field;        /* LATTICE2D: the uniform bias h of E = sum J s s - h sum s (0 without) */
+    double jabs_y;       /* LATTICE2D: |J| of the vertical bonds (jabs is then the horizontal bonds'; equal unless fast_path == 3) */
 } isingmc_graph_info_t;
 
 const char *isingmc_last_error(void);
@@ -84,8 +86,9 @@ int isingmc_host_expand_schedule(const uint64_t *stop_t, const double *stop_beta
                                  size_t timesteps, int compat_constant_beta, double *betas_out);
 
 /* Recogniser: is this edge list a W x H square lattice with ids y*W+x, every bond present once,
- * uniform |J|, periodic or open (ALL wrap-around bonds of a direction absent) in each direction?
- * *is_lattice = 0 when not (then the general path is used), else 1 + 2 (open in x) + 4 (open in y). */
+ * one |J| per direction, periodic or open (ALL wrap-around bonds of a direction absent) in each direction?
+ * *is_lattice = 0 when not (then the general path is used), else 1 + 2 (open in x) + 4 (open in y)
+ * + 8 (|J| of the horizontal bonds, returned in *jabs, differs from the vertical bonds'). */
 int isingmc_host_recognise_lattice2d(const uint64_t *edge_a, const uint64_t *edge_b,
                                      const double *edge_j, size_t n_edges, size_t nvars,
                                      int *is_lattice, int *width, int *height, double *jabs,

@@ -390,17 +390,17 @@ static void lat_bond_counts(const lat_geom *g, const uint32_t *state, const uint
                             const uint8_t *jdown, int jpos_uniform, int open_x, int open_y, int y, int x,
                             int *sat, int *unsat)
 {
+    /* sat[0], unsat[0]: the horizontal bonds; sat[1], unsat[1]: the vertical bonds */
     int W = g->W, H = g->H;
     int s = lat_get(g, state, y, x);
     int xl = (x + W - 1) % W, xr = (x + 1) % W, yu = (y + H - 1) % H, yd = (y + 1) % H;
-    int k = 0, u = 0, ok;
+    int ok;
+    sat[0] = sat[1] = unsat[0] = unsat[1] = 0;
     /* a bond with J>0 is satisfied when the spins differ, with J<0 when they agree */
-    if (!(open_x && x == W - 1)) { ok = (s != lat_get(g, state, y, xr)) == bond_pos(jright, jpos_uniform, W, y, x); k += ok; u += !ok; }
-    if (!(open_x && x == 0)) { ok = (s != lat_get(g, state, y, xl)) == bond_pos(jright, jpos_uniform, W, y, xl); k += ok; u += !ok; }
-    if (!(open_y && y == H - 1)) { ok = (s != lat_get(g, state, yd, x)) == bond_pos(jdown, jpos_uniform, W, y, x); k += ok; u += !ok; }
-    if (!(open_y && y == 0)) { ok = (s != lat_get(g, state, yu, x)) == bond_pos(jdown, jpos_uniform, W, yu, x); k += ok; u += !ok; }
-    *sat = k;
-    *unsat = u;
+    if (!(open_x && x == W - 1)) { ok = (s != lat_get(g, state, y, xr)) == bond_pos(jright, jpos_uniform, W, y, x); sat[0] += ok; unsat[0] += !ok; }
+    if (!(open_x && x == 0)) { ok = (s != lat_get(g, state, y, xl)) == bond_pos(jright, jpos_uniform, W, y, xl); sat[0] += ok; unsat[0] += !ok; }
+    if (!(open_y && y == H - 1)) { ok = (s != lat_get(g, state, yd, x)) == bond_pos(jdown, jpos_uniform, W, y, x); sat[1] += ok; unsat[1] += !ok; }
+    if (!(open_y && y == 0)) { ok = (s != lat_get(g, state, yu, x)) == bond_pos(jdown, jpos_uniform, W, yu, x); sat[1] += ok; unsat[1] += !ok; }
 }
 
 /*
@@ -411,10 +411,12 @@ static void lat_bond_counts(const lat_geom *g, const uint32_t *state, const uint
  * u = (N_PLANES-bit prefix from the quad's bit-planes) << 32 | (32-bit residual word, drawn only when T is not
  * "always" and the prefix equals the threshold's top N_PLANES bits: a "tie"; the n-th tie of the quad in (word, bit)
  * order takes word n%4 of call N_PLANES + n/4).  Periodic, h = 0: dE = 2|J|(2k-4), the k = 3, 4 classes of round 1.
+ * Anisotropic (jabs_y >= 0: the vertical bonds' |J|, jabs then the horizontal bonds'):
+ * dE = 2|Jx|(sat_x - unsat_x) + 2|Jy|(sat_y - unsat_y) + 2 h s.
  */
-void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
-                      const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
-                      uint64_t t, double beta)
+void orc_lat_sweep_ex2(int W, int H, double jabs, double jabs_y, int jpos_uniform, const uint8_t *jright,
+                       const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
+                       uint64_t t, double beta)
 {
     lat_geom g = lat_make(W, H);
     const uint64_t ONE = (uint64_t)1 << THR_BITS;
@@ -435,10 +437,12 @@ void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t
                 for (int b = 0; b < 32; b++) {
                     int i = 32 * xw + b;
                     int x = 2 * i + ((y + (int)c) & 1);
-                    int sat, unsat;
-                    lat_bond_counts(&g, state, jright, jdown, jpos_uniform, open_x, open_y, y, x, &sat, &unsat);
+                    int sat[2], unsat[2];
+                    lat_bond_counts(&g, state, jright, jdown, jpos_uniform, open_x, open_y, y, x, sat, unsat);
                     double sval = lat_get(&g, state, y, x) ? 1.0 : -1.0;
-                    double dE = 2.0 * jabs * (double)(sat - unsat) + 2.0 * h * sval;
+                    double dE = jabs_y < 0.0
+                        ? 2.0 * jabs * (double)(sat[0] + sat[1] - unsat[0] - unsat[1]) + 2.0 * h * sval
+                        : 2.0 * jabs * (double)(sat[0] - unsat[0]) + 2.0 * jabs_y * (double)(sat[1] - unsat[1]) + 2.0 * h * sval;
                     uint64_t T = orc_threshold_fixed(beta, dE);
                     int accept;
                     if (T == ONE) accept = 1;
@@ -466,32 +470,49 @@ void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t
     }
 }
 
+void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                      const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
+                      uint64_t t, double beta)
+{
+    orc_lat_sweep_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, open_x, open_y, state, seed, t, beta);
+}
+
 void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
                    const uint8_t *jdown, uint32_t *state, uint64_t seed, uint64_t t, double beta)
 {
     orc_lat_sweep_ex(W, H, jabs, jpos_uniform, jright, jdown, 0.0, 0, 0, state, seed, t, beta);
 }
 
-/* E = sum over existing bonds of J s s (J = +-jabs) - h sum s, and M = sum s, from the packed state */
-void orc_lat_energy_mag_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
-                           const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
-                           double *energy, int64_t *mag)
+/* E = sum over existing bonds of J s s (J = +-jabs; anisotropic, jabs_y >= 0: +-jabs horizontally, +-jabs_y vertically)
+ * - h sum s, and M = sum s, from the packed state */
+void orc_lat_energy_mag_ex2(int W, int H, double jabs, double jabs_y, int jpos_uniform, const uint8_t *jright,
+                            const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
+                            double *energy, int64_t *mag)
 {
     lat_geom g = lat_make(W, H);
-    int64_t unsat_minus_sat = 0, m = 0;
+    int64_t ums[2] = {0, 0}, m = 0;
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             int s = lat_get(&g, state, y, x);
             m += s ? 1 : -1;
             int sr = lat_get(&g, state, y, (x + 1) % W), sd = lat_get(&g, state, (y + 1) % H, x);
             if (!(open_x && x == W - 1))
-                unsat_minus_sat += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
+                ums[0] += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
             if (!(open_y && y == H - 1))
-                unsat_minus_sat += ((s != sd) == bond_pos(jdown, jpos_uniform, W, y, x)) ? -1 : 1;
+                ums[1] += ((s != sd) == bond_pos(jdown, jpos_uniform, W, y, x)) ? -1 : 1;
         }
-    /* the two terms separately, then one subtraction: the engine forms the same expression from its counters */
-    if (energy) *energy = jabs * (double)unsat_minus_sat - h * (double)m;
+    /* the terms separately, then one subtraction: the engine forms the same expression from its counters */
+    if (energy)
+        *energy = jabs_y < 0.0 ? jabs * (double)(ums[0] + ums[1]) - h * (double)m
+                               : jabs * (double)ums[0] + jabs_y * (double)ums[1] - h * (double)m;
     if (mag) *mag = m;
+}
+
+void orc_lat_energy_mag_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
+                           const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
+                           double *energy, int64_t *mag)
+{
+    orc_lat_energy_mag_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, open_x, open_y, state, energy, mag);
 }
 
 void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,

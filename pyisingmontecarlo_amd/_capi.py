@@ -17,7 +17,7 @@ class GraphInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("device", C.c_int32), ("nvars", C.c_uint64), ("n_edges", C.c_uint64),
                 ("width", C.c_int32), ("height", C.c_int32), ("jabs", C.c_double), ("uniform_sign", C.c_int32),
                 ("n_colours", C.c_uint32), ("state_words", C.c_uint64), ("fast_path", C.c_int32), ("open_x", C.c_int32),
-                ("open_y", C.c_int32), ("field", C.c_double)]
+                ("open_y", C.c_int32), ("field", C.c_double), ("jabs_y", C.c_double)]
 
 
 _vp = C.c_void_p
@@ -155,8 +155,10 @@ def recognise_lattice2d(ea, eb, ej, nvars):
     _check(lib().isingmc_host_recognise_lattice2d(_p(ea), _p(eb), _p(ej), len(ea), nvars, C.byref(ok), C.byref(w),
                                                   C.byref(h), C.byref(jabs), C.byref(u)))
     out = dict(is_lattice=bool(ok.value), width=w.value, height=h.value, jabs=jabs.value, uniform_sign=bool(u.value))
-    if ok.value > 1:  # open boundaries (all wrap-around bonds of a direction absent)
+    if (ok.value - 1) & 6 > 0:  # open boundaries (all wrap-around bonds of a direction absent)
         out.update(open_x=bool((ok.value - 1) & 2), open_y=bool((ok.value - 1) & 4))
+    if ok.value > 0 and (ok.value - 1) & 8:  # jabs is the horizontal bonds' |J|, the vertical bonds have another
+        out.update(anisotropic=True)
     return out
 
 

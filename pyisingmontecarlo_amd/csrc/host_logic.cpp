@@ -99,7 +99,7 @@ Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const doub
     if (H < 4 || (H & 1) || (W & 1) || W > (1u << 30) || H > (1u << 30)) return out;
 
     std::vector<uint8_t> seen(2 * N, 0), jpos(2 * N, 0);
-    const double jabs = std::fabs(ej[0]);
+    double jabs_dir[2] = {-1.0, -1.0}; // |J| of the horizontal / vertical bonds: one value per direction
     bool any_pos = false, any_neg = false;
     for (size_t k = 0; k < n_edges; k++) {
         const uint64_t lo = std::min(ea[k], eb[k]), hi = std::max(ea[k], eb[k]);
@@ -113,7 +113,9 @@ Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const doub
         else return out;
         if (seen[slot]) return out;
         seen[slot] = 1;
-        if (!(std::fabs(ej[k]) == jabs)) return out; // uniform |J| only (NaN fails too)
+        double &jd = jabs_dir[slot & 1];
+        if (jd < 0.0) jd = std::fabs(ej[k]);
+        if (!(std::fabs(ej[k]) == jd)) return out; // one |J| per direction only (NaN fails too)
         const bool pos = ej[k] > 0.0;
         jpos[slot] = pos;
         (pos ? any_pos : any_neg) = true;
@@ -132,7 +134,8 @@ Lattice2D recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const doub
     out.ok = true;
     out.W = int(W);
     out.H = int(H);
-    out.jabs = jabs;
+    out.jabs = jabs_dir[0];
+    out.jabs_y = jabs_dir[1];
     out.open_x = wrap_x == 0;
     out.open_y = wrap_y == 0;
     out.uniform_sign = !(any_pos && any_neg);

@@ -25,7 +25,8 @@ std::string expand_schedule(const uint64_t *stop_t, const double *stop_beta, siz
 struct Lattice2D {
     bool ok = false;
     int W = 0, H = 0;
-    double jabs = 0.0;
+    double jabs = 0.0;                  // |J| of the horizontal bonds (of every bond when isotropic)
+    double jabs_y = 0.0;                // |J| of the vertical bonds
     bool uniform_sign = true;
     bool jpos_uniform = false;          // sign when uniform: true = J > 0 (antiferromagnetic)
     bool open_x = false, open_y = false; // no bonds between columns W-1 and 0 / rows H-1 and 0 (all of them absent)

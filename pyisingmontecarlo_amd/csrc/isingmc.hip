@@ -69,6 +69,7 @@ struct isingmc_graph {
     uint32_t *d_jneg = nullptr; // [2 colours][4 directions][wpp]
     // multi-class checkerboard kernels (mc_types.hpp): uniform field or open boundaries on a recognised lattice
     int mc_mode = MC_NONE;
+    double jabs_y = 0.0;  // MC_ANISO: |J| of the vertical bonds (jabs = the horizontal ones')
     double field = 0.0;   // MC_FIELD: h of E = sum J s s - h sum s
     McOpen open{0, 0};    // MC_OPEN
     // general path
@@ -263,10 +264,13 @@ static LatThr lattice_thresholds(double beta, double jabs)
 static LatThrMC lattice_thresholds_mc(const isingmc_graph *g, double beta)
 {
     LatThrMC t{};
-    const int nc = g->mc_mode == MC_FIELD ? 6 : 4;
+    const int nc = g->mc_mode == MC_FIELD ? 6 : g->mc_mode == MC_ANISO ? 5 : 4;
     for (int c = 0; c < nc; c++) {
         double dE;
-        if (g->mc_mode == MC_FIELD) {
+        if (g->mc_mode == MC_ANISO) {
+            static const int mx[5] = {2, 2, 0, 2, -2}, my[5] = {2, 0, 2, -2, 2}; // (sat - unsat) per direction of the classes
+            dE = 2.0 * g->jabs * double(mx[c]) + 2.0 * g->jabs_y * double(my[c]); // the oracle's expression, term by term
+        } else if (g->mc_mode == MC_FIELD) {
             const int k = 2 + c / 2;
             const double sval = (c & 1) ? 1.0 : -1.0;
             dE = 2.0 * g->jabs * double(2 * k - 4) + 2.0 * g->field * sval; // the oracle's expression: 2|J|(sat - unsat) + 2 h s
@@ -284,6 +288,10 @@ static LatThrMC lattice_thresholds_mc(const isingmc_graph *g, double beta)
 // lattice energy from the integer counters: E = |J| (bonds - 2 satisfied) - h (2 up - N)   (exact in f64 for h = 0)
 static double lattice_energy(const isingmc_graph *g, unsigned long long sat, unsigned long long up)
 {
+    if (g->mc_mode == MC_ANISO) { // sat = satisfied horizontal | satisfied vertical << 32; N bonds per direction
+        const int64_t n = int64_t(g->nvars), sx = int64_t(sat & 0xFFFFFFFFull), sy = int64_t(sat >> 32);
+        return g->jabs * double(n - 2 * sx) + g->jabs_y * double(n - 2 * sy);
+    }
     const double bonds = g->jabs * double(int64_t(g->n_edges) - 2 * int64_t(sat));
     if (g->mc_mode != MC_FIELD) return bonds;
     return bonds - g->field * double(2 * int64_t(up) - int64_t(g->nvars));
@@ -390,7 +398,8 @@ extern "C" int isingmc_host_recognise_lattice2d(const uint64_t *ea, const uint64
     if (!is_lattice) return fail(ISINGMC_ERR_INVALID, "is_lattice is NULL");
     TRY(check_edges(ea, eb, ej, n_edges, nvars));
     const Lattice2D L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    *is_lattice = L.ok ? 1 + 2 * int(L.open_x) + 4 * int(L.open_y) : 0; // bit 0: a W x H lattice; bits 1, 2: open in x, y
+    // bit 0: a W x H lattice; bits 1, 2: open in x, y; bit 3: |J| differs between the directions
+    *is_lattice = L.ok ? 1 + 2 * int(L.open_x) + 4 * int(L.open_y) + 8 * int(L.jabs != L.jabs_y) : 0;
     if (width) *width = L.W;
     if (height) *height = L.H;
     if (jabs) *jabs = L.jabs;
@@ -440,10 +449,11 @@ static bool lattice_fast_path_ok(const Lattice2D &L, double h)
 {
     if (!L.ok || L.W % 64 != 0) return false;
     if (std::isnan(h)) return false;
-    const bool open = L.open_x || L.open_y;
-    if (open && h != 0.0) return false;
+    const bool open = L.open_x || L.open_y, aniso = L.jabs != L.jabs_y;
+    if (int(open) + int(h != 0.0) + int(aniso) > 1) return false; // one generalisation at a time
     if (h != 0.0 && !(std::fabs(h) <= 2.0 * L.jabs)) return false;
-    if ((open || h != 0.0) && (L.W / 64) % 4 != 0) return false;
+    if ((open || h != 0.0 || aniso) && (L.W / 64) % 4 != 0) return false;
+    if (aniso && uint64_t(L.W) * uint64_t(L.H) >= (uint64_t(1) << 32)) return false; // two 32-bit bond counters in one word
     const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
     // the kernels address a replica through ONE buffer descriptor (int num_records) and 32-bit byte offsets:
     // both planes must fit below 2^31 bytes; larger lattices take the general path
@@ -453,7 +463,8 @@ static bool lattice_fast_path_ok(const Lattice2D &L, double h)
 static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h)
 {
     g->kind = ISINGMC_KIND_LATTICE2D;
-    g->mc_mode = h != 0.0 ? MC_FIELD : (L.open_x || L.open_y) ? MC_OPEN : MC_NONE;
+    g->mc_mode = h != 0.0 ? MC_FIELD : (L.open_x || L.open_y) ? MC_OPEN : L.jabs != L.jabs_y ? MC_ANISO : MC_NONE;
+    g->jabs_y = L.jabs_y;
     g->field = h;
     g->open = McOpen{uint32_t(L.open_x), uint32_t(L.open_y)};
     LatGeom &G = g->geom;
@@ -649,6 +660,7 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
         info->width = int32_t(g->geom.W);
         info->height = int32_t(g->geom.H);
         info->jabs = g->jabs;
+        info->jabs_y = g->mc_mode == MC_ANISO ? g->jabs_y : g->jabs;
         info->uniform_sign = g->uniform_sign;
         info->fast_path = g->mc_mode;
         info->field = g->field;
@@ -1186,6 +1198,11 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
     for (size_t r0 = 0; r0 < s->R; r0 += MAX_GRID_Y) {
         const size_t n = std::min(MAX_GRID_Y, s->R - r0);
         const uint32_t blocks = (g->geom.nquads + 256 * MEASURE_QUADS_PER_THREAD - 1) / (256 * MEASURE_QUADS_PER_THREAD);
+        if (g->mc_mode == MC_ANISO) { // the two directions' bonds carry different |J|: counted apart
+            (void)mc_launch_measure_aniso(PMJ, dim3(blocks, unsigned(n)), s->stream, s->d_state + r0 * g->state_words, g->geom, g->d_jneg,
+                                          g->jneg_uniform, out + r0 * out_stride, out_stride);
+            continue;
+        }
         if (g->mc_mode == MC_OPEN) { // the bonds across the open boundary do not exist: they must not count as satisfied
             (void)mc_launch_measure_open(PMJ, dim3(blocks, unsigned(n)), s->stream, s->d_state + r0 * g->state_words, g->geom, g->d_jneg,
                                          g->jneg_uniform, g->open, out + r0 * out_stride, out_stride);

@@ -31,6 +31,15 @@ __device__ __forceinline__ void mc_classes(const uint32_t own, const uint32_t a0
         mask[0] = e2 & ~own; mask[1] = e2 & own;
         mask[2] = e3 & ~own; mask[3] = e3 & own;
         mask[4] = e4 & ~own; mask[5] = e4 & own;
+    } else if constexpr (MODE == MC_ANISO) {
+        // a0 = up, a1 = down (vertical, |Jy|); a2 = centre, a3 = side (horizontal, |Jx|)
+        const uint32_t kx2 = a2 & a3, kx1 = a2 ^ a3, kx0 = ~(a2 | a3), ky2 = a0 & a1, ky1 = a0 ^ a1, ky0 = ~(a0 | a1);
+        mask[0] = kx2 & ky2;
+        mask[1] = kx2 & ky1;
+        mask[2] = kx1 & ky2;
+        mask[3] = kx2 & ky0;
+        mask[4] = kx0 & ky2;
+        mask[5] = 0;
     } else {
         // a0 = up, a1 = down, a2 = centre (always exists), a3 = side
         const uint32_t s0 = a0 & p_up, s1 = a1 & p_dn, s2 = a2, s3 = a3 & p_si;
@@ -50,7 +59,7 @@ __device__ __forceinline__ void mc_classes(const uint32_t own, const uint32_t a0
 
 template <int MODE>
 struct McInfo {
-    static constexpr int NC = MODE == MC_FIELD ? 6 : 4;
+    static constexpr int NC = MODE == MC_FIELD ? 6 : MODE == MC_ANISO ? 5 : 4;
 };
 
 // presence masks of word w (global word index in the plane's row y, first word xw + q) for open boundaries
@@ -169,6 +178,52 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
         }
     }
     mem.store4(widx[0], make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]));
+}
+
+// lat_measure_kernel with the satisfied horizontal and vertical bonds counted apart (they carry different |J|)
+template <bool PMJ>
+__global__ __launch_bounds__(256) void lat_mc_measure_aniso_kernel(
+    const uint32_t *__restrict__ state, const LatGeom g, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
+    unsigned long long *__restrict__ out, const size_t out_stride)
+{
+    __shared__ uint32_t red[3][4];
+    const uint32_t r = blockIdx.y;
+    uint32_t satx = 0, saty = 0, up = 0;
+    const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
+    for (uint32_t i = 0; i < MEASURE_QUADS_PER_THREAD; i++) {
+        const uint32_t gid = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
+        if (gid >= g.nquads) break;
+        uint32_t Q, qy, qxw, own[4], widx[4];
+        thread_to_quad<false>(g, gid, Q, qy, qxw);
+        QuadNbr n;
+        load_quad<true, false>(PtrPlanes{const_cast<uint32_t *>(p0), p0 + g.wpp}, g, 0, Q, qy, qxw, own, n, widx);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t a0, a1, a2, a3;
+            bond_masks<PMJ>(own[q], n, q, jneg, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+            saty += __popc(a0) + __popc(a1);
+            satx += __popc(a2) + __popc(a3);
+            up += __popc(own[q]) + __popc(n.ce[q]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        satx += __shfl_xor(satx, off);
+        saty += __shfl_xor(saty, off);
+        up += __shfl_xor(up, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = satx;
+        red[1][threadIdx.x >> 6] = saty;
+        red[2][threadIdx.x >> 6] = up;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long sx = (unsigned long long)red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const unsigned long long sy = (unsigned long long)red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        atomicAdd(out + size_t(r) * out_stride, sx | (sy << 32)); // a lattice of < 2^32 spins: the halves cannot carry into each other
+        atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)(red[2][0] + red[2][1] + red[2][2] + red[2][3]));
+    }
 }
 
 // lat_measure_kernel with the open boundaries' missing bonds left out (colour-0 sites, their four directions)

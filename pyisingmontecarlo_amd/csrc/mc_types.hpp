@@ -9,12 +9,14 @@ namespace isingmc {
 
 struct LatGeom;
 
-enum : int { MC_NONE = 0, MC_FIELD = 1, MC_OPEN = 2 };
+enum : int { MC_NONE = 0, MC_FIELD = 1, MC_OPEN = 2, MC_ANISO = 3 };
 constexpr int MC_MAX_CLASSES = 6;
 
 // Acceptance classes of a spin.  MC_FIELD (periodic, |h| <= 2|J|): class 2 (k - 2) + s for k = 2, 3, 4 satisfied bonds
 // and spin bit s -- flipping costs dE = 2|J|(2k - 4) + 2 h (2s - 1); k < 2 always flips.  MC_OPEN (no field, bonds
 // across the open boundary absent): class m - 1 for m = satisfied - unsatisfied EXISTING bonds = 1 .. 4, dE = 2|J| m.
+// MC_ANISO (periodic, no field, |Jx| != |Jy|): classes by (kx, ky) = satisfied horizontal / vertical bonds:
+// 0 (2,2), 1 (2,1), 2 (1,2), 3 (2,0), 4 (0,2); dE = 2 (|Jx| (2 kx - 2) + |Jy| (2 ky - 2)); every other pair has dE <= 0.
 // Per class: the top N_PLANES bits and the low 32 bits of T = floor(exp(-beta dE) 2^THR_BITS); bit c of `costly` is
 // clear where the class flips outright (dE <= 0 or T = 2^THR_BITS).
 struct LatThrMC {
@@ -29,6 +31,9 @@ struct McOpen {
 hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
                            uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
                            const uint32_t *jneg, uint32_t jneg_uniform, McOpen open);
+// MC_ANISO: out[r * stride] += satisfied horizontal bonds | satisfied vertical bonds << 32, out[r * stride + 1] += up spins
+hipError_t mc_launch_measure_aniso(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
+                                   uint32_t jneg_uniform, unsigned long long *out, size_t out_stride);
 // satisfied EXISTING bonds and up spins per replica: out[r * stride] += sat, out[r * stride + 1] += up
 hipError_t mc_launch_measure_open(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
                                   uint32_t jneg_uniform, McOpen open, unsigned long long *out, size_t out_stride);

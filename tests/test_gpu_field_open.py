@@ -187,3 +187,77 @@ def test_tempering_on_a_field_lattice_uses_the_host_swap_step(capi, exact):
         pt.add_graph(float(b))
     pt.timesteps(20, replica_swap_freq=2)
     assert not pt._on_stream and pt.get_total_swaps() > 0 and sorted(pt.get_permutation()) == list(range(6))
+
+
+def _aniso_edges(exact, W, H, jx, jy, rng):
+    """Right bonds +-jx, down bonds +-jy (signs: all negative, or random when rng)."""
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0, rng)
+    ej = ej.copy()
+    ej[0::2] *= jx
+    ej[1::2] *= jy
+    return ea, eb, ej
+
+
+@pytest.mark.parametrize("W,H", [(256, 16), (512, 32), (1024, 8)])
+@pytest.mark.parametrize("jx,jy", [(1.0, 0.5), (0.3, 1.7), (1.0, 3.0), (2.0, 1.0), (1.0, 0.0)])
+@pytest.mark.parametrize("glass", [False, True])
+def test_anisotropic_couplings_bit_exact(capi, oracle, exact, W, H, jx, jy, glass):
+    """|J| differs between the horizontal and the vertical bonds: five classes (kx, ky) of the multi-class kernel,
+    dE = 2|Jx|(sat_x - unsat_x) + 2|Jy|(sat_y - unsat_y); the energy from two bond counters."""
+    ea, eb, ej = _aniso_edges(exact, W, H, jx, jy, np.random.default_rng(W + H) if glass else None)
+    perm = np.random.default_rng(3).permutation(len(ea))
+    a, b, j = ea[perm], eb[perm], ej[perm]
+    r = capi.recognise_lattice2d(a, b, j, W * H)
+    assert r["is_lattice"] and r.get("anisotropic") and r["jabs"] == jx
+    g = capi.Graph(a, b, j)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == 3 and (g.info.jabs, g.info.jabs_y) == (jx, jy)
+    if glass:
+        lat = oracle.Lat(W, H, jx, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), jabs_y=jy)
+    else:
+        lat = oracle.Lat(W, H, jx, 0, jabs_y=jy)
+    _check(capi, oracle, g, lat, a, b, j, W * H, None, 5, np.array([0.0, 0.3, 0.4407, 1.2, 3.0]))
+
+
+def test_anisotropic_per_replica_betas_sampling_and_general_fallbacks(capi, oracle, exact):
+    W, H, jx, jy = 256, 32, 0.8, 1.3
+    ea, eb, ej = _aniso_edges(exact, W, H, jx, jy, None)
+    ej = -ej                                                          # antiferromagnetic
+    g = capi.Graph(ea, eb, ej)
+    assert g.info.fast_path == 3
+    lat = oracle.Lat(W, H, jx, 1, jabs_y=jy)
+    st = capi.States(g, SEEDS)
+    betas = [0.3, 1.1, -0.4]
+    st.set_betas(betas)
+    st.do_time_steps(6)
+    for r, s in enumerate(SEEDS):
+        ref = lat.init(s)
+        for t in range(6):
+            lat.sweep(ref, s, t, betas[r])
+        np.testing.assert_array_equal(st.packed()[r], ref)
+        assert st.energies()[r] == lat.energy_mag(ref)[0]
+    # anisotropy together with a field or open boundaries, or a third |J|: the general path
+    assert capi.Graph(ea, eb, ej, biases=np.full(W * H, 0.2)).kind == capi.KIND_GENERAL
+    keep = ~((ea % W == W - 1) & (eb % W == 0))
+    assert capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H).kind == capi.KIND_GENERAL
+    ej3 = ej.copy(); ej3[4] *= 2.0
+    assert not capi.recognise_lattice2d(ea, eb, ej3, W * H)["is_lattice"]
+    assert capi.Graph(ea, eb, ej3).kind == capi.KIND_GENERAL
+
+
+def test_anisotropic_decoupled_chains_match_the_exact_energy(capi, exact):
+    """Independent check of the anisotropic kernel's physics against an exact result: for |Jy| = 0 the rows are
+    independent periodic chains, whose energy per bond is -|Jx| tanh(beta |Jx|) up to O(tanh^W) corrections."""
+    W, H, jx, beta = 256, 64, 1.0, 0.7
+    ea, eb, ej = _aniso_edges(exact, W, H, jx, 0.0, None)
+    g = capi.Graph(ea, eb, ej)
+    assert g.info.fast_path == 3
+    st = capi.States(g, np.arange(16, dtype=np.uint64) + 5)
+    st.do_time_steps(400, beta)
+    acc = []
+    for _ in range(40):
+        st.do_time_steps(10, beta)
+        acc.append(st.energies().mean())
+    e_bond = np.mean(acc) / (W * H)
+    expect = -jx * math.tanh(beta * jx)
+    # 16 replicas x 40 samples x 16384 bonds; chain energy variance per bond = J^2 sech^2 ~ 0.63 -> sigma ~ 2.5e-4 (correlated: x3)
+    assert abs(e_bond - expect) < 2.5e-3, (e_bond, expect)

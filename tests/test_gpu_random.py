@@ -137,11 +137,16 @@ def test_random_strip_lattices(capi, oracle, exact, wq, rows, pm, R, T, beta, nw
 @settings(max_examples=25, **COMMON)
 @given(wq=st.sampled_from([4, 8, 12]), H=st.sampled_from([4, 6, 16, 34]), pm=st.booleans(), R=st.integers(1, 4), T=st.integers(0, 5),
        beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0, -0.3]), jabs=st.sampled_from([1.0, 0.3]),
-       mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy"]), seed=st.integers(0, 2 ** 64 - 1))
+       mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy", "aniso_x", "aniso_y"]),
+       seed=st.integers(0, 2 ** 64 - 1))
 def test_random_field_and_open_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, mode, seed):
-    """Multi-class checkerboard kernels on random geometries, couplings, fields and boundary conditions."""
+    """Multi-class checkerboard kernels on random geometries, couplings, fields, boundary conditions and anisotropies."""
     W = 64 * wq
     ea, eb, ej = exact.square_lattice_edges(W, H, jabs if pm else -jabs, np.random.default_rng(seed % 2 ** 32) if pm else None)
+    jy = {"aniso_x": 0.45 * jabs, "aniso_y": 2.75 * jabs}.get(mode)         # |J| of the vertical bonds, when it differs
+    if jy is not None:
+        ej = ej.copy()
+        ej[1::2] *= jy / jabs
     h = {"field+": 0.37 * jabs, "field-": -1.3 * jabs, "field_max": 2.0 * jabs}.get(mode, 0.0)
     ox, oy = mode in ("open_x", "open_xy"), mode in ("open_y", "open_xy")
     keep = np.ones(len(ea), dtype=bool)
@@ -150,8 +155,8 @@ def test_random_field_and_open_lattices(capi, oracle, exact, wq, H, pm, R, T, be
     if oy:
         keep &= ~((ea // W == H - 1) & (eb // W == 0))
     graph = capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=np.full(W * H, h) if h else None)
-    assert graph.kind == capi.KIND_LATTICE2D and graph.info.fast_path == (1 if h else 2)
-    kw = dict(field=h, open_x=ox, open_y=oy)
+    assert graph.kind == capi.KIND_LATTICE2D and graph.info.fast_path == (1 if h else 3 if jy is not None else 2)
+    kw = dict(field=h, open_x=ox, open_y=oy, jabs_y=jy)
     lat = (oracle.Lat(W, H, jabs, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), **kw) if pm
            else oracle.Lat(W, H, jabs, 0, **kw))
     seeds = capi.make_seeds(seed, R)

@@ -96,6 +96,19 @@ def test_recogniser_accepts_any_edge_order_and_orientation(capi, exact):
     assert r["is_lattice"] and not r["uniform_sign"] and r["jabs"] == 1.0
 
 
+def test_recogniser_accepts_one_coupling_strength_per_direction(capi, exact):
+    W, H = 64, 8
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0, np.random.default_rng(2))
+    ej = ej.copy(); ej[0::2] *= 0.5; ej[1::2] *= 2.5              # right bonds |J| = 0.5, down bonds |J| = 2.5
+    perm = np.random.default_rng(0).permutation(len(ea))
+    r = capi.recognise_lattice2d(eb[perm], ea[perm], ej[perm], W * H)
+    assert r["is_lattice"] and r["anisotropic"] and r["jabs"] == 0.5 and not r["uniform_sign"]
+    ej2 = ej.copy(); ej2[6] = 2.5                                    # a horizontal bond with the vertical bonds' |J|
+    assert not capi.recognise_lattice2d(ea, eb, ej2, W * H)["is_lattice"]
+    ea1, eb1, ej1 = exact.square_lattice_edges(W, H, 1.0)
+    assert "anisotropic" not in capi.recognise_lattice2d(ea1, eb1, ej1, W * H)
+
+
 def test_recogniser_rejects_non_lattices(capi, exact):
     W, H = 64, 8
     ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)

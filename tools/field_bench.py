@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SURVEY 8f-4 at BASELINE c2's size: 4096^2 x 256 replicas with a uniform field (Lattice.set_global_bias(0.25)) and with
-open boundaries -- multi-class checkerboard kernels vs the plain periodic lattice and vs the general (CSR) path."""
+open boundaries, or anisotropic couplings -- multi-class checkerboard kernels vs the plain periodic lattice and vs the general (CSR) path."""
 import os
 import sys
 
@@ -19,10 +19,15 @@ open_keep = ~((ea % L == L - 1) & (eb % L == 0)) & ~((ea // L == L - 1) & (eb //
 cases = [("periodic, h = 0", dict(), R, steps),
          ("uniform field h = 0.25", dict(biases=np.full(N, 0.25)), R, steps),
          ("open boundaries (x and y)", dict(keep=open_keep), R, steps),
+         ("anisotropic |Jy| = 0.5 |Jx|", dict(jy=0.5), R, steps),
          ("uniform field h = 0.25, general path", dict(biases=np.full(N, 0.25), force_general=True), 16, 3)]
 for name, kw, reps, T in cases:
     keep = kw.pop("keep", None)
     a, b, j = (ea, eb, ej) if keep is None else (ea[keep], eb[keep], ej[keep])
+    jy = kw.pop("jy", None)
+    if jy is not None:
+        j = j.copy()
+        j[1::2] *= jy                    # square(): right and down bonds alternate
     g = _capi.Graph(a, b, j, nvars=N, **kw)
     st = _capi.States(g, _capi.make_seeds(1, reps))
     st.do_time_steps(3, BETA)
