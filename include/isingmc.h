@@ -66,6 +66,8 @@ typedef struct {
     int32_t open_x, open_y; /* LATTICE2D: no bonds between columns W-1 and 0 / rows H-1 and 0 */
     double field;        /* LATTICE2D: the uniform bias h of E = sum J s s - h sum s (0 without) */
     double jabs_y;       /* LATTICE2D: |J| of the vertical bonds (jabs is then the horizontal bonds'; equal unless fast_path == 3) */
+    int32_t packed_degree; /* GENERAL: d in 3..6 when the replica-packed path may use its one-degree kernel
+                              (every site has d neighbours, every coupling the same size), else 0 */
 } isingmc_graph_info_t;
 
 const char *isingmc_last_error(void);

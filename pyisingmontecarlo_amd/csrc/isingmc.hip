@@ -82,6 +82,11 @@ struct isingmc_graph {
     // replica-packed variant of the general path (uniform |J|, no fields, degree <= PK_MAX_DEG)
     bool packed_ok = false;
     PkGraphDev pk{};
+    // every real site has this degree (3..6): packed_uni_kernels.hpp; 0 otherwise
+    int pk_uni_deg = 0;
+    bool pk_uni_pmj = false;             // couplings of both signs
+    PkUniHeaders pk_uni{};
+    std::vector<uint32_t> pk_class_full; // per colour class: end of its last 256-block without padding
     uint64_t n_directed = 0;
     std::vector<void *> dev_allocs;
 
@@ -609,6 +614,40 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
             g->packed_ok = true;
             g->jabs = jabs;
             g->n_directed = nbr.size();
+            // one degree, one sign?  (isolated sites have degree 0: they rule the uniform kernel out too)
+            uint64_t mindeg = maxdeg;
+            for (size_t i = 0; i < nvars; i++) mindeg = std::min(mindeg, A.ptr[i + 1] - A.ptr[i]);
+            bool one_sign = true;
+            for (double x : w) one_sign &= (x > 0.0) == (w[0] > 0.0);
+            if (mindeg == maxdeg && maxdeg >= 3) {
+                g->pk_uni_deg = int(maxdeg);
+                g->pk_uni_pmj = !one_sign;
+                g->pk_uni.negmask = w[0] > 0.0 ? 0u : 0xFFFFFFFFu;
+                // this kernel's block headers: translations whatever the signs, the signs as one 64-bit mask per block and slot
+                std::vector<uint2> shift(n_blocks * PK_MAX_DEG, make_uint2(PK_HDR_MIXED, 0)), sign(n_blocks * PK_MAX_DEG, make_uint2(0, 0));
+                parallel_for(n_blocks, [&](size_t B) {
+                    for (uint32_t i = 0; i < uint32_t(maxdeg); i++) {
+                        const uint32_t *e = ell.data() + size_t(i) * n_pos + 64 * B;
+                        const uint32_t p0 = uint32_t(64 * B), delta = (e[0] & 0x7FFFFFFFu) - p0;
+                        bool translation = true;
+                        uint64_t mask = 0;
+                        for (uint32_t l = 0; l < 64; l++) {
+                            translation &= e[l] != PK_NO_NBR && (e[l] & 0x7FFFFFFFu) - (p0 + l) == delta;
+                            mask |= uint64_t(e[l] != PK_NO_NBR && (e[l] >> 31)) << l;
+                        }
+                        if (translation) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, delta);
+                        sign[B * PK_MAX_DEG + i] = make_uint2(uint32_t(mask), uint32_t(mask >> 32));
+                    }
+                });
+                TRY(graph_upload(g, &g->pk_uni.shift, shift));
+                TRY(graph_upload(g, &g->pk_uni.sign, sign));
+                g->pk_class_full.resize(C.n_colours);
+                for (uint32_t c = 0; c < C.n_colours; c++) { // real sites come first in a class, the padding after them
+                    uint32_t real = 0;
+                    while (uint32_t(C.class_base[c]) + real < uint32_t(C.class_base[c + 1]) && site[uint32_t(C.class_base[c]) + real] != PAD_SITE) real++;
+                    g->pk_class_full[c] = uint32_t(C.class_base[c]) + real / 256 * 256;
+                }
+            }
         }
     }
     D.bias = nullptr;
@@ -668,6 +707,7 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
         info->open_y = int32_t(g->open.open_y);
     }
     info->n_colours = g->n_colours;
+    info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
     info->state_words = g->state_words;
     return ISINGMC_OK;
 }
@@ -1003,11 +1043,20 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
         if (e == b) continue;
+        // blocks of real sites of a one-degree graph: the specialised kernel; the class's padded tail (and
+        // every other graph): the general one.  tab_stride == 0 <=> one table, one beta for every replica.
+        static const bool no_uni = env_flag("ISINGMC_DISABLE_PACKED_UNIFORM"); // A/B switch: results are the same either way
+        const uint32_t mid = g->pk_uni_deg && !no_uni ? g->pk_class_full[c] : b;
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
-            hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - b) / 1024 + ((e - b) % 1024 != 0), unsigned(ng)), dim3(256), 0, s->stream,
-                               s->d_state + g0 * g->pk.n_pos, g->pk, b, e, s->t, s->d_keys + g0,
-                               tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
+            if (mid > b)
+                (void)pk_uni_launch_sweep(g->pk_uni_deg, tab_stride == 0, g->pk_uni_pmj, dim3((mid - b) / 1024 + ((mid - b) % 1024 != 0), unsigned(ng)),
+                                          s->stream, s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
+                                          tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
+            if (e > mid)
+                hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - mid) / 1024 + ((e - mid) % 1024 != 0), unsigned(ng)), dim3(256), 0, s->stream,
+                                   s->d_state + g0 * g->pk.n_pos, g->pk, mid, e, s->t, s->d_keys + g0,
+                                   tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
         }
     }
 }

@@ -21,31 +21,9 @@
 //   lo[m-1][r]          low 32 bits of T_m(beta_r)
 #pragma once
 #include "lattice_kernels.hpp"
+#include "packed_types.hpp"
 
 namespace isingmc {
-
-constexpr int PK_MAX_DEG = 6;
-constexpr uint32_t DOM_PK_SWEEP = 0x504B5357u; // "PKSW"
-constexpr uint32_t DOM_PK_INIT = 0x504B494Eu;  // "PKIN"
-constexpr uint32_t PK_TAB_ALL = 0, PK_TAB_TBW = PK_MAX_DEG, PK_TAB_LO = PK_MAX_DEG + PK_MAX_DEG * N_PLANES;
-constexpr uint32_t PK_TAB_WORDS = PK_TAB_LO + PK_MAX_DEG * 32;
-
-constexpr uint32_t PK_NO_NBR = 0xFFFFFFFFu;
-
-// Block headers of the ELL table: block B = positions [64 B, 64 B + 64) -- exactly what the 64 lanes of a wave
-// touch for one word of their quads.  Where a slot's 64 entries are one translation (same offset to the own
-// position, same coupling sign: the interior of any lattice-like graph) or all unused, the header replaces
-// them: the wave reads 8 bytes through the scalar unit instead of 256 from the table.
-constexpr uint32_t PK_HDR_MIXED = 0, PK_HDR_UNIFORM = 1, PK_HDR_UNUSED = 2; // .x bits 0-1; .x bit 31 = J > 0; .y = offset
-
-struct PkGraphDev {
-    const uint2 *ell_hdr;       // [n_pos / 64][PK_MAX_DEG]
-    const uint32_t *nbr_ell;    // [PK_MAX_DEG][n_pos]: neighbour position | (J > 0) << 31, or PK_NO_NBR
-    const uint32_t *site;       // original site per position, PAD_SITE on padding
-    const uint32_t *class_base; // n_colours + 1, multiples of 256
-    uint32_t n_colours;
-    uint32_t n_pos;             // multiple of 256
-};
 
 // ELL slot of position p: from the (wave-uniform) block header where the block is a translation or unused,
 // else from the table

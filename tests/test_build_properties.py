@@ -53,3 +53,20 @@ def test_packed_sweep_kernel_keeps_eight_waves(device_asm):
     gains (the kernel is bound by the latency of its dependent memory phases): +2 % on 256^3 x 64."""
     for name, vgpr, spill, scratch in _kernel_meta(device_asm, "_ZN7isingmc15pk_sweep_kernel"):
         assert vgpr <= 64 and spill <= 4 and scratch <= 32, f"{name}: {vgpr} VGPRs, {spill} spills, {scratch} B scratch"
+
+
+def test_packed_uniform_degree_kernels_keep_eight_waves(tmp_path):
+    """pk_sweep_uni_kernel<D, UB, PMJ>: at most a few spilled registers at __launch_bounds__(256, 8) (<6, true, true> spills
+    three, like the general packed kernel)."""
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "pku.s"
+    src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "packed_uni_kernels.hip")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    metas = _kernel_meta(out.read_text(), "_ZN7isingmc19pk_sweep_uni_kernel")
+    assert len(metas) == 16
+    for name, vgpr, spill, scratch in metas:
+        assert vgpr <= 64 and spill <= 4 and scratch <= 32, f"{name}: {vgpr} VGPRs, {spill} spills, {scratch} B scratch"
+        if "ELb0EEE" in name:  # one coupling sign: the c5 kernels
+            assert spill == 0 and scratch == 0, f"{name}: spills"

@@ -353,6 +353,38 @@ def test_packed_general_path_bit_exact(capi, oracle, exact, monkeypatch):
         st.append(5)
 
 
+def _circulant(n, offsets, J):
+    """Site i bonded to i + d (mod n) for d in offsets; d == n/2 gives one bond per pair: every site has the same degree."""
+    ea, eb = [], []
+    for d in offsets:
+        idx = np.arange(n if 2 * d != n else n // 2, dtype=np.uint64)
+        ea.append(idx)
+        eb.append((idx + d) % n)
+    ea, eb = np.concatenate(ea), np.concatenate(eb)
+    return ea, eb, np.full(len(ea), J)
+
+
+@pytest.mark.parametrize("deg,n,offsets", [(3, 3000, (1, 1500)), (4, 2900, (1, 2)), (5, 3400, (1, 2, 1700)), (6, 3700, (1, 2, 3)),
+                                           (6, 2048, (1, 5, 11))])
+@pytest.mark.parametrize("J", [-1.0, 0.6, "glass"])
+def test_packed_uniform_degree_kernels_bit_exact(capi, oracle, monkeypatch, deg, n, offsets, J):
+    """One degree: pk_sweep_uni_kernel<D, UB, PMJ> (packed_uni_kernels.hpp) on the full 256-blocks of every colour class,
+    the general packed kernel on the padded tails -- against oracle engine D, with one coupling sign or random signs
+    (PMJ), one beta for all replicas (UB), a beta schedule, and per-replica betas."""
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    ea, eb, ej = _circulant(n, offsets, 1.3 if J == "glass" else J)
+    if J == "glass":
+        ej = ej * np.random.default_rng(n).choice([-1.0, 1.0], len(ej))
+    g = capi.Graph(ea, eb, ej, nvars=n)
+    assert g.kind == capi.KIND_GENERAL and g.info.packed_degree == deg
+    _packed_case(capi, oracle, ea, eb, ej, n, R=40, T=6, beta=0.35)
+    _packed_case(capi, oracle, ea, eb, ej, n, R=33, T=5, beta=np.array([0.0, 0.1, 0.25, 0.6, 2.0]))
+    _packed_case(capi, oracle, ea, eb, ej, n, R=64, T=5, beta_replica=np.linspace(-0.2, 1.4, 64))
+    # a site of another degree: the general kernel (packed_degree == 0), same oracle
+    assert capi.Graph(ea[1:], eb[1:], ej[1:], nvars=n).info.packed_degree == 0
+    _packed_case(capi, oracle, ea[1:], eb[1:], ej[1:], n, R=20, T=3, beta=0.35)
+
+
 def test_packed_path_equilibrium_vs_kaufman(capi, exact, monkeypatch):
     """K3 for the packed path: 32x32 torus (general path: not 64-wide), 64 replicas."""
     monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")

@@ -1,8 +1,11 @@
 #!/bin/bash
-# SQ counter passes for the sweep kernel (per-launch means printed as JSON)
+# SQ counter passes for the sweep kernel (per-launch means printed as JSON): tools/pmc_sq.sh <tag> [<python script> [args]]
+# default command: bench.py --steps 20 --warmup 2 --no-cpu-baseline; KFILTER=<substring of the kernel name> (default lat_sweep)
 set -uo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq_$1; shift
+if [ $# -eq 0 ]; then set -- bench.py --steps 20 --warmup 2 --no-cpu-baseline; fi
+export KFILTER=${KFILTER:-lat_sweep}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -10,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WA
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
            "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/p$i.log" 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/$1" "${@:2}" > "$OUT/p$i.log" 2>&1
   echo "pass $i done"
 done
 python3 - "$OUT" <<'PY'
@@ -20,7 +23,7 @@ acc = defaultdict(list)
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "lat_sweep" in r["Kernel_Name"]:
+            if os.environ["KFILTER"] in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(json.dumps({k: sum(v) / len(v) for k, v in sorted(acc.items())}, indent=1))
 PY
