@@ -1040,12 +1040,12 @@ static int pk_set_betas(isingmc_states *s)
 static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride)
 {
     const isingmc_graph *g = s->g;
+    const bool no_uni = env_flag("ISINGMC_DISABLE_PACKED_UNIFORM"); // A/B switch: results are the same either way
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
         if (e == b) continue;
         // blocks of real sites of a one-degree graph: the specialised kernel; the class's padded tail (and
         // every other graph): the general one.  tab_stride == 0 <=> one table, one beta for every replica.
-        static const bool no_uni = env_flag("ISINGMC_DISABLE_PACKED_UNIFORM"); // A/B switch: results are the same either way
         const uint32_t mid = g->pk_uni_deg && !no_uni ? g->pk_class_full[c] : b;
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);

@@ -380,6 +380,14 @@ def test_packed_uniform_degree_kernels_bit_exact(capi, oracle, monkeypatch, deg,
     _packed_case(capi, oracle, ea, eb, ej, n, R=40, T=6, beta=0.35)
     _packed_case(capi, oracle, ea, eb, ej, n, R=33, T=5, beta=np.array([0.0, 0.1, 0.25, 0.6, 2.0]))
     _packed_case(capi, oracle, ea, eb, ej, n, R=64, T=5, beta_replica=np.linspace(-0.2, 1.4, 64))
+    out = []                                                          # the same binary with the general kernel: equal
+    for disable in ("0", "1"):
+        monkeypatch.setenv("ISINGMC_DISABLE_PACKED_UNIFORM", disable)
+        st = capi.States(g, capi.make_seeds(3, 96))
+        st.do_time_steps(7, 0.45)
+        out.append(st.states().copy())
+    monkeypatch.delenv("ISINGMC_DISABLE_PACKED_UNIFORM")
+    np.testing.assert_array_equal(out[0], out[1])
     # a site of another degree: the general kernel (packed_degree == 0), same oracle
     assert capi.Graph(ea[1:], eb[1:], ej[1:], nvars=n).info.packed_degree == 0
     _packed_case(capi, oracle, ea[1:], eb[1:], ej[1:], n, R=20, T=3, beta=0.35)
