@@ -3,16 +3,26 @@
 
 namespace isingmc {
 
-hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
-                           uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
-                           const uint32_t *jneg, uint32_t jneg_uniform, McOpen open)
+template <int MODE>
+static void launch_mode(bool pmj, bool uni, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour, uint64_t t,
+                        const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica, const uint32_t *jneg,
+                        uint32_t jneg_uniform, McOpen open)
 {
     const auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
     };
-    if (mode == MC_FIELD) { if (pmj) launch(lat_mc_sweep_kernel<MC_FIELD, true>); else launch(lat_mc_sweep_kernel<MC_FIELD, false>); }
-    else if (mode == MC_ANISO) { if (pmj) launch(lat_mc_sweep_kernel<MC_ANISO, true>); else launch(lat_mc_sweep_kernel<MC_ANISO, false>); }
-    else { if (pmj) launch(lat_mc_sweep_kernel<MC_OPEN, true>); else launch(lat_mc_sweep_kernel<MC_OPEN, false>); }
+    if (uni) { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, true>); else launch(lat_mc_sweep_kernel<MODE, false, true>); }
+    else { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, false>); else launch(lat_mc_sweep_kernel<MODE, false, false>); }
+}
+
+hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
+                           uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
+                           const uint32_t *jneg, uint32_t jneg_uniform, McOpen open)
+{
+    const bool uni = g.cols_log2 >= 0; // the 2^k mapping of the streaming kernels applies (build_lattice)
+    if (mode == MC_FIELD) launch_mode<MC_FIELD>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
+    else if (mode == MC_ANISO) launch_mode<MC_ANISO>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
+    else launch_mode<MC_OPEN>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
     return hipGetLastError();
 }
 

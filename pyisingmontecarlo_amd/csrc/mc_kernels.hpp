@@ -79,7 +79,9 @@ __device__ __forceinline__ void mc_presence(const LatGeom &g, const McOpen open,
     }
 }
 
-template <int MODE, bool PMJ>
+// UNI: the division-free, wave-uniform thread -> quad mapping of the streaming kernels (load_quad_uni; the host
+// passes it when g.cols_log2 >= 0); else thread_to_quad / load_quad.  Same quads either way.
+template <int MODE, bool PMJ, bool UNI>
 __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t, const uint2 *__restrict__ keys,
     const LatThrMC thr_uniform, const LatThrMC *__restrict__ thr_replica, const uint32_t *__restrict__ jneg,
@@ -88,27 +90,42 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     constexpr int NC = McInfo<MODE>::NC;
     const uint32_t r = blockIdx.y;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    // per-replica thresholds are wave-uniform: scalar loads
+    const LatThrMC *tp = thr_replica ? thr_replica + r : &thr_uniform;
+    __shared__ uint32_t lo_tab[8]; // low threshold words by class, for the tie stage (one replica per workgroup)
+    if (threadIdx.x < 8) lo_tab[threadIdx.x] = threadIdx.x < uint32_t(NC) ? tp->lo[threadIdx.x] : 0u;
+    __syncthreads();
     if (gid >= g.nquads) return;
     uint32_t *mine = state + size_t(r) * 2 * g.wpp;
     const PtrPlanes mem{mine + size_t(colour) * g.wpp, mine + size_t(1 - colour) * g.wpp};
+    BufPlanes bmem;
+    if constexpr (UNI) {
+        bmem.rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
+        bmem.own_off = colour * g.wpp * 4u;
+        bmem.oth_off = (1 - colour) * g.wpp * 4u;
+    }
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
-    // per-replica thresholds are wave-uniform: scalar loads
-    const LatThrMC *tp = thr_replica ? thr_replica + r : &thr_uniform;
-    uint32_t hi[NC], lo[NC];
+    uint32_t hi[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        hi[c] = __builtin_amdgcn_readfirstlane(tp->hi[c]);
-        lo[c] = __builtin_amdgcn_readfirstlane(tp->lo[c]);
-    }
+    for (int c = 0; c < NC; c++) hi[c] = __builtin_amdgcn_readfirstlane(tp->hi[c]);
     const uint32_t costly = __builtin_amdgcn_readfirstlane(tp->costly);
 
-    uint32_t Q, qy, qxw, own[4], widx[4];
-    thread_to_quad<false>(g, gid, Q, qy, qxw);
+    uint32_t Q, qy, qxw, own[4], widx[4], vQ = 0;
     QuadNbr n;
     QuadSigns js;
-    load_signs<PMJ>(PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, g, Q, js);
-    load_quad<true, false>(mem, g, colour, Q, qy, qxw, own, n, widx);
+    if constexpr (UNI) {
+        load_quad_uni(bmem, g, colour, gid, Q, vQ, own, n);
+        qy = Q >> uint32_t(g.cols_log2);
+        qxw = (Q & ((1u << uint32_t(g.cols_log2)) - 1)) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) widx[q] = 4 * Q + q;
+        load_signs<PMJ>(PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, g, Q, js);
+    } else {
+        thread_to_quad<false>(g, gid, Q, qy, qxw);
+        load_signs<PMJ>(PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, g, Q, js);
+        load_quad<true, false>(mem, g, colour, Q, qy, qxw, own, n, widx);
+    }
 
     uint32_t mask[4][NC], lt[4], und[4];
 #pragma unroll
@@ -157,27 +174,41 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] |= lt[q];
+#ifdef ISINGMC_TIMING_ONLY_NO_TIES // diagnostic build: what the tie stage costs (results are wrong without it)
+    if (false) {
+#else
     if (und[0] | und[1] | und[2] | und[3]) { // ties: the n-th of the quad in (word, bit) order takes word n % 4 of call N_PLANES + n / 4
+#endif
         uint32_t nres = 0;
         uint4 w = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+        // the class of a tied spin as a 3-bit index from three bit-planes per word; its threshold's low word from a
+        // table in LDS (one read instead of a select per class)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t m = und[q];
+            if (!m) continue;
+            uint32_t k0 = mask[q][1] | mask[q][3], k1 = mask[q][2] | mask[q][3], k2 = 0;
+            if constexpr (NC > 4) { k2 = mask[q][4]; }
+            if constexpr (NC > 5) { k0 |= mask[q][5]; k2 |= mask[q][5]; }
             while (m) {
                 const uint32_t b = __ffs(m) - 1;
                 m &= m - 1;
                 if (nres != 0 && (nres & 3u) == 0)
                     w = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
-                uint32_t lo_c = 0;
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    if ((mask[q][c] >> b) & 1u) lo_c = lo[c];
+                const uint32_t idx = ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2);
+                const uint32_t lo_c = lo_tab[idx];
                 if (sel4(w, nres & 3u) < lo_c) acc[q] |= 1u << b;
                 nres++;
             }
         }
     }
-    mem.store4(widx[0], make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]));
+    const uint4 out = make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]);
+    if constexpr (UNI) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{out.x, out.y, out.z, out.w}, bmem.rsrc, vQ, bmem.own_off, 0);
+    } else {
+        mem.store4(widx[0], out);
+    }
 }
 
 // lat_measure_kernel with the satisfied horizontal and vertical bonds counted apart (they carry different |J|)

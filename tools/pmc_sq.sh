@@ -19,11 +19,12 @@ done
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
-acc = defaultdict(list)
+acc = defaultdict(lambda: defaultdict(list))  # kernel name (up to its argument list) -> counter -> values
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
             if os.environ["KFILTER"] in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-print(json.dumps({k: sum(v) / len(v) for k, v in sorted(acc.items())}, indent=1))
+                acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {name: {k: sum(v) / len(v) for k, v in sorted(c.items())} for name, c in sorted(acc.items())}
+print(json.dumps(next(iter(out.values())) if len(out) == 1 else out, indent=1))
 PY
