@@ -83,15 +83,34 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_kernel(uint32_t *__restrict__
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
+    // All 24 block headers first (scalar loads, one wait); then straight-line code: a slot is (own position + the header's
+    // shift) | sign for translation blocks, all ones (PK_NO_NBR) for unused ones -- both from scalars -- and where the block
+    // is neither, a branch holding nothing but a load overwrites it with the table entry (a header load or a use of the
+    // loaded value per slot made the wave wait for memory 24 times).
     uint32_t own[4], x[4][PK_MAX_DEG], nb[4][PK_MAX_DEG];
-#pragma unroll
-    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+    uint2 h[4][PK_MAX_DEG];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint2 *hdr = G.ell_hdr + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
 #pragma unroll
-        for (int i = 0; i < PK_MAX_DEG; i++) x[q][i] = pk_slot(hdr[i], ell_rsrc, uint32_t(i) * G.n_pos, p0 + 64 * q);
+        for (int i = 0; i < PK_MAX_DEG; i++) h[q][i] = hdr[i];
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < PK_MAX_DEG; i++) {
+            const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x), hy = __builtin_amdgcn_readfirstlane(h[q][i].y);
+            const uint32_t fill = (hx & 3u) == PK_HDR_UNUSED ? PK_NO_NBR : (hx & 0x80000000u); // scalar
+            x[q][i] = (p0 + 64 * q + hy) | fill;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < PK_MAX_DEG; i++)
+            if ((__builtin_amdgcn_readfirstlane(h[q][i].x) & 3u) == PK_HDR_MIXED)
+                x[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0);
 #pragma unroll
     for (int i = 0; i < PK_MAX_DEG; i++)
 #pragma unroll

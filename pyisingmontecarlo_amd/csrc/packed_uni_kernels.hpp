@@ -97,27 +97,34 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
 
-    // memory phase: own words, then the byte offsets of the D neighbours of each position (translation blocks: a scalar
-    // added to the own offset; other blocks: the table entry, whose sign bit the shift drops), then the gathers
-    uint32_t own[4], off[4][PK_MAX_DEG], nb[4][PK_MAX_DEG];
-#pragma unroll
-    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+    // memory phase.  All 24 block headers first (scalar loads, one wait), then straight-line code: the neighbour's
+    // position is own position + the header's shift; where a block is not a translation a branch holding nothing but a
+    // load overwrites it with the table entry (a use of the loaded value inside the branch, or a header load per slot,
+    // makes the wave wait for memory once per slot); then the gathers (the shift to a byte offset drops the sign bit).
+    uint32_t own[4], ent[4][PK_MAX_DEG], nb[4][PK_MAX_DEG];
+    uint2 h[4][PK_MAX_DEG];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint2 *hdr = H.shift + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const uint2 h = hdr[i];
-            if (__builtin_amdgcn_readfirstlane(h.x) == PK_HDR_UNIFORM)
-                off[q][i] = 4 * (p0 + 64 * q) + 4 * h.y;
-            else
-                off[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0) << 2;
-        }
+        for (int i = 0; i < D; i++) h[q][i] = hdr[i];
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < D; i++) ent[q][i] = p0 + 64 * q + uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y));
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (__builtin_amdgcn_readfirstlane(h[q][i].x) != PK_HDR_UNIFORM)
+                ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0);
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, off[q][i], 0, 0);
+        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, ent[q][i] << 2, 0, 0);
 
     // classes
     uint32_t eq[4][3], lt[4], und[4], sure[4]; // sure: flips whatever the random numbers say
