@@ -13,3 +13,12 @@ ClassicIsing = _ext.ClassicIsing
 from pyisingmontecarlo_amd.tempering import ClassicalTempering  # noqa: E402
 
 __all__ = ["Lattice", "ClassicIsing", "ClassicalTempering"]
+
+_QUANTUM_ONLY = ("QmcIsing", "QmcRunner", "LatticeTempering")  # src/lib.rs:16-21
+
+
+def __getattr__(name):
+    if name in _QUANTUM_ONLY:
+        raise NotImplementedError(f"py_monte_carlo.{name}: quantum (SSE) Monte Carlo is not part of this build "
+                                  "(classical Metropolis only: Lattice, ClassicIsing, ClassicalTempering)")
+    raise AttributeError(f"module 'py_monte_carlo' has no attribute {name!r}")

@@ -583,6 +583,19 @@ PYBIND11_MODULE(_py_monte_carlo, m)
              "betas"_a, "timesteps"_a, "num_experiments"_a, "only_basic_moves"_a = py::none(),
              "edge_move_importance_sampling"_a = py::none(), "replica_range"_a = py::none())
         .def("clone", &Lattice::clone);
+    // the reference's quantum (SSE) entry points (lattice.rs:478-1036) live in the un-vendored qmc crate and are out of
+    // scope: present by name, so a script written for the reference fails with a reason instead of an AttributeError
+    for (const char *name : {"run_quantum_monte_carlo", "run_quantum_monte_carlo_sampling",
+                             "run_quantum_monte_carlo_and_measure_variable_autocorrelation",
+                             "run_quantum_monte_carlo_and_measure_spin_product_autocorrelation",
+                             "run_quantum_monte_carlo_and_measure_bond_autocorrelation",
+                             "run_quantum_monte_carlo_and_measure_spins", "get_offset", "average_on_and_off_diagonal_and_consts"}) {
+        const std::string what = std::string("Lattice.") + name + ": quantum (SSE) Monte Carlo is not part of this build (classical Metropolis only)";
+        py::setattr(m.attr("Lattice"), name, py::cpp_function([what](const py::args &, const py::kwargs &) -> py::object {
+                        PyErr_SetString(PyExc_NotImplementedError, what.c_str());
+                        throw py::error_already_set();
+                    }, py::is_method(m.attr("Lattice"))));
+    }
 
     py::class_<ClassicIsing>(m, "ClassicIsing")
         .def(py::init<const py::object &, std::optional<double>, std::optional<size_t>, std::optional<uint64_t>,

@@ -21,6 +21,21 @@ def _sig(fn):
     return fn.__doc__.splitlines()[0]
 
 
+def test_quantum_entry_points_fail_with_a_reason(mod):
+    """lattice.rs:478-1036 and lib.rs:16-21: out of scope, but present by name."""
+    import py_monte_carlo
+    lat = mod.Lattice([((0, 1), 1.0)])
+    for name in ("run_quantum_monte_carlo", "run_quantum_monte_carlo_sampling", "run_quantum_monte_carlo_and_measure_spins",
+                 "get_offset", "average_on_and_off_diagonal_and_consts"):
+        with pytest.raises(NotImplementedError, match="quantum"):
+            getattr(lat, name)(1.0, 10, 2)
+    for name in ("QmcIsing", "QmcRunner", "LatticeTempering"):
+        with pytest.raises(NotImplementedError, match="quantum"):
+            getattr(py_monte_carlo, name)
+    with pytest.raises(AttributeError):
+        py_monte_carlo.no_such_thing
+
+
 def test_lattice_signatures(mod):
     L = mod.Lattice
     # lattice.rs:46-50, 171-179, 231-241, 309-317, 395-403: order and names of the reference's parameters
