@@ -62,10 +62,12 @@ typedef struct {
     uint64_t state_words;/* 32-bit words of packed spin state per replica */
     int32_t fast_path;   /* LATTICE2D: 0 = periodic, no field; 1 = uniform field (set_global_bias, lattice.rs:129-131;
                             ClassicIsing longitudinal, classicising.rs:69); 2 = open boundaries;
-                            3 = anisotropic (|J| of the horizontal bonds != |J| of the vertical ones) */
+                            3 = anisotropic (|J| of the horizontal bonds != |J| of the vertical ones);
+                            4 = open boundaries and a field */
     int32_t open_x, open_y; /* LATTICE2D: no bonds between columns W-1 and 0 / rows H-1 and 0 */
     double field;        /* LATTICE2D: the uniform bias h of E = sum J s s - h sum s (0 without) */
     double jabs_y;       /* LATTICE2D: |J| of the vertical bonds (jabs is then the horizontal bonds'; equal unless fast_path == 3) */
+    int32_t field_signs; /* LATTICE2D: 1 when the biases are +-field from site to site (sign planes), field = |h| then */
     int32_t packed_degree; /* GENERAL: d in 3..6 when the replica-packed path may use its one-degree kernel
                               (every site has d neighbours, every coupling the same size), else 0 */
 } isingmc_graph_info_t;

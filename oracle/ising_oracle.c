@@ -415,9 +415,10 @@ static void lat_bond_counts(const lat_geom *g, const uint32_t *state, const uint
  * dE = 2|Jx|(sat_x - unsat_x) + 2|Jy|(sat_y - unsat_y) + 2 h s.
  */
 void orc_lat_sweep_ex2(int W, int H, double jabs, double jabs_y, int jpos_uniform, const uint8_t *jright,
-                       const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
-                       uint64_t t, double beta)
+                       const uint8_t *jdown, double h, const uint8_t *hneg, int open_x, int open_y, uint32_t *state,
+                       uint64_t seed, uint64_t t, double beta)
 {
+    /* hneg (optional, [H*W]): 1 where the site's field is -h instead of +h (fields of one size and both signs) */
     lat_geom g = lat_make(W, H);
     const uint64_t ONE = (uint64_t)1 << THR_BITS;
     size_t nquads = g.wpp / 4;
@@ -440,9 +441,10 @@ void orc_lat_sweep_ex2(int W, int H, double jabs, double jabs_y, int jpos_unifor
                     int sat[2], unsat[2];
                     lat_bond_counts(&g, state, jright, jdown, jpos_uniform, open_x, open_y, y, x, sat, unsat);
                     double sval = lat_get(&g, state, y, x) ? 1.0 : -1.0;
+                    double hi_ = (hneg && hneg[(size_t)y * W + x]) ? -h : h;
                     double dE = jabs_y < 0.0
-                        ? 2.0 * jabs * (double)(sat[0] + sat[1] - unsat[0] - unsat[1]) + 2.0 * h * sval
-                        : 2.0 * jabs * (double)(sat[0] - unsat[0]) + 2.0 * jabs_y * (double)(sat[1] - unsat[1]) + 2.0 * h * sval;
+                        ? 2.0 * jabs * (double)(sat[0] + sat[1] - unsat[0] - unsat[1]) + 2.0 * hi_ * sval
+                        : 2.0 * jabs * (double)(sat[0] - unsat[0]) + 2.0 * jabs_y * (double)(sat[1] - unsat[1]) + 2.0 * hi_ * sval;
                     uint64_t T = orc_threshold_fixed(beta, dE);
                     int accept;
                     if (T == ONE) accept = 1;
@@ -474,7 +476,7 @@ void orc_lat_sweep_ex(int W, int H, double jabs, int jpos_uniform, const uint8_t
                       const uint8_t *jdown, double h, int open_x, int open_y, uint32_t *state, uint64_t seed,
                       uint64_t t, double beta)
 {
-    orc_lat_sweep_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, open_x, open_y, state, seed, t, beta);
+    orc_lat_sweep_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, NULL, open_x, open_y, state, seed, t, beta);
 }
 
 void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,
@@ -486,15 +488,16 @@ void orc_lat_sweep(int W, int H, double jabs, int jpos_uniform, const uint8_t *j
 /* E = sum over existing bonds of J s s (J = +-jabs; anisotropic, jabs_y >= 0: +-jabs horizontally, +-jabs_y vertically)
  * - h sum s, and M = sum s, from the packed state */
 void orc_lat_energy_mag_ex2(int W, int H, double jabs, double jabs_y, int jpos_uniform, const uint8_t *jright,
-                            const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
-                            double *energy, int64_t *mag)
+                            const uint8_t *jdown, double h, const uint8_t *hneg, int open_x, int open_y,
+                            const uint32_t *state, double *energy, int64_t *mag)
 {
     lat_geom g = lat_make(W, H);
-    int64_t ums[2] = {0, 0}, m = 0;
+    int64_t ums[2] = {0, 0}, m = 0, mh = 0; /* mh = sum of s_i x sign of the site's field */
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             int s = lat_get(&g, state, y, x);
             m += s ? 1 : -1;
+            mh += (s != 0) != (hneg && hneg[(size_t)y * W + x]) ? 1 : -1;
             int sr = lat_get(&g, state, y, (x + 1) % W), sd = lat_get(&g, state, (y + 1) % H, x);
             if (!(open_x && x == W - 1))
                 ums[0] += ((s != sr) == bond_pos(jright, jpos_uniform, W, y, x)) ? -1 : 1;
@@ -503,8 +506,8 @@ void orc_lat_energy_mag_ex2(int W, int H, double jabs, double jabs_y, int jpos_u
         }
     /* the terms separately, then one subtraction: the engine forms the same expression from its counters */
     if (energy)
-        *energy = jabs_y < 0.0 ? jabs * (double)(ums[0] + ums[1]) - h * (double)m
-                               : jabs * (double)ums[0] + jabs_y * (double)ums[1] - h * (double)m;
+        *energy = jabs_y < 0.0 ? jabs * (double)(ums[0] + ums[1]) - h * (double)mh
+                               : jabs * (double)ums[0] + jabs_y * (double)ums[1] - h * (double)mh;
     if (mag) *mag = m;
 }
 
@@ -512,7 +515,7 @@ void orc_lat_energy_mag_ex(int W, int H, double jabs, int jpos_uniform, const ui
                            const uint8_t *jdown, double h, int open_x, int open_y, const uint32_t *state,
                            double *energy, int64_t *mag)
 {
-    orc_lat_energy_mag_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, open_x, open_y, state, energy, mag);
+    orc_lat_energy_mag_ex2(W, H, jabs, -1.0, jpos_uniform, jright, jdown, h, NULL, open_x, open_y, state, energy, mag);
 }
 
 void orc_lat_energy_mag(int W, int H, double jabs, int jpos_uniform, const uint8_t *jright,

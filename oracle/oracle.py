@@ -59,9 +59,10 @@ def lib():
         L.orc_lat_energy_mag_ex.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_int, C.c_int, u32p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.orc_lat_sweep_ex2.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
-                                        C.c_int, C.c_int, u32p, C.c_uint64, C.c_uint64, C.c_double]
+                                        C.c_void_p, C.c_int, C.c_int, u32p, C.c_uint64, C.c_uint64, C.c_double]
         L.orc_lat_energy_mag_ex2.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_double, C.c_int, C.c_int, u32p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+                                             C.c_double, C.c_void_p, C.c_int, C.c_int, u32p, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int64)]
         L.orc_det_exp.restype = C.c_double
         L.orc_det_exp.argtypes = [C.c_double]
         L.orc_gen_colouring.restype = C.c_uint32
@@ -149,10 +150,13 @@ def det_exp(x):
 class Lat:
     """Checkerboard spec engine (engine B) for one replica of a periodic W x H lattice."""
 
-    def __init__(self, W, H, jabs=1.0, jpos_uniform=0, jright=None, jdown=None, field=0.0, open_x=False, open_y=False, jabs_y=None):
+    def __init__(self, W, H, jabs=1.0, jpos_uniform=0, jright=None, jdown=None, field=0.0, open_x=False, open_y=False, jabs_y=None,
+                 field_neg=None):
         """field: uniform h of E = sum J s s - h sum s; open_x / open_y: no bonds between columns W-1 and 0 / rows H-1 and 0;
         jabs_y: |J| of the vertical bonds when it differs from the horizontal bonds' (jabs)."""
         self.jabs_y = -1.0 if jabs_y is None else float(jabs_y)
+        # field_neg: uint8[H*W], 1 where the site's field is -field instead of +field
+        self.field_neg = None if field_neg is None else np.ascontiguousarray(field_neg, dtype=np.uint8).ravel()
         assert lib().orc_lat_supported(W, H), (W, H)
         self.W, self.H, self.jabs, self.jpos = W, H, float(jabs), int(jpos_uniform)
         self.field, self.open_x, self.open_y = float(field), int(bool(open_x)), int(bool(open_y))
@@ -177,12 +181,12 @@ class Lat:
 
     def sweep(self, st, seed, t, beta):
         lib().orc_lat_sweep_ex2(self.W, self.H, self.jabs, self.jabs_y, self.jpos, _ptr(self.jright), _ptr(self.jdown), self.field,
-                               self.open_x, self.open_y, st, C.c_uint64(int(seed)), C.c_uint64(int(t)), float(beta))
+                                _ptr(self.field_neg), self.open_x, self.open_y, st, C.c_uint64(int(seed)), C.c_uint64(int(t)), float(beta))
 
     def energy_mag(self, st):
         e, m = C.c_double(), C.c_int64()
         lib().orc_lat_energy_mag_ex2(self.W, self.H, self.jabs, self.jabs_y, self.jpos, _ptr(self.jright), _ptr(self.jdown), self.field,
-                                    self.open_x, self.open_y, st, C.byref(e), C.byref(m))
+                                     _ptr(self.field_neg), self.open_x, self.open_y, st, C.byref(e), C.byref(m))
         return e.value, m.value
 
 

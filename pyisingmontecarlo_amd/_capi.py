@@ -18,7 +18,7 @@ class GraphInfo(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("jabs", C.c_double), ("uniform_sign", C.c_int32),
                 ("n_colours", C.c_uint32), ("state_words", C.c_uint64), ("fast_path", C.c_int32), ("open_x", C.c_int32),
                 ("open_y", C.c_int32), ("field", C.c_double), ("jabs_y", C.c_double),
-                ("packed_degree", C.c_int32)]
+                ("field_signs", C.c_int32), ("packed_degree", C.c_int32)]
 
 
 _vp = C.c_void_p

@@ -71,7 +71,8 @@ struct isingmc_graph {
     int mc_mode = MC_NONE;
     double jabs_y = 0.0;  // MC_ANISO: |J| of the vertical bonds (jabs = the horizontal ones')
     double field = 0.0;   // MC_FIELD: h of E = sum J s s - h sum s
-    McOpen open{0, 0};    // MC_OPEN
+    McOpen open{0, 0, 0}; // MC_OPEN, MC_FIELD_OPEN
+    uint32_t *d_fneg = nullptr; // fields of one size and both signs: sign planes [2][wpp] (bit set where h_i < 0); field = |h| then
     // general path
     GenGraphDev gdev{};
     bool w_is_float = false;
@@ -269,10 +270,14 @@ static LatThr lattice_thresholds(double beta, double jabs)
 static LatThrMC lattice_thresholds_mc(const isingmc_graph *g, double beta)
 {
     LatThrMC t{};
-    const int nc = g->mc_mode == MC_FIELD ? 6 : g->mc_mode == MC_ANISO ? 5 : 4;
+    const int nc = g->mc_mode == MC_FIELD_OPEN ? 9 : g->mc_mode == MC_FIELD ? 6 : g->mc_mode == MC_ANISO ? 5 : 4;
     for (int c = 0; c < nc; c++) {
         double dE;
-        if (g->mc_mode == MC_ANISO) {
+        if (g->mc_mode == MC_FIELD_OPEN) { // classes by m = sat - unsat and sigma = spin x sign of the site's field: |h| here
+            const int m = c < 8 ? 1 + c / 2 : 0;
+            const double sval = (c == 8 || (c & 1)) ? 1.0 : -1.0;
+            dE = 2.0 * g->jabs * double(m) + 2.0 * std::fabs(g->field) * sval;
+        } else if (g->mc_mode == MC_ANISO) {
             static const int mx[5] = {2, 2, 0, 2, -2}, my[5] = {2, 0, 2, -2, 2}; // (sat - unsat) per direction of the classes
             dE = 2.0 * g->jabs * double(mx[c]) + 2.0 * g->jabs_y * double(my[c]); // the oracle's expression, term by term
         } else if (g->mc_mode == MC_FIELD) {
@@ -297,8 +302,12 @@ static double lattice_energy(const isingmc_graph *g, unsigned long long sat, uns
         const int64_t n = int64_t(g->nvars), sx = int64_t(sat & 0xFFFFFFFFull), sy = int64_t(sat >> 32);
         return g->jabs * double(n - 2 * sx) + g->jabs_y * double(n - 2 * sy);
     }
+    if (g->d_fneg) { // sat = satisfied bonds | spins along their site's field << 32; field = |h|
+        const int64_t k = int64_t(sat & 0xFFFFFFFFull), along = int64_t(sat >> 32);
+        return g->jabs * double(int64_t(g->n_edges) - 2 * k) - g->field * double(2 * along - int64_t(g->nvars));
+    }
     const double bonds = g->jabs * double(int64_t(g->n_edges) - 2 * int64_t(sat));
-    if (g->mc_mode != MC_FIELD) return bonds;
+    if (g->mc_mode != MC_FIELD && g->mc_mode != MC_FIELD_OPEN) return bonds;
     return bonds - g->field * double(2 * int64_t(up) - int64_t(g->nvars));
 }
 
@@ -438,25 +447,37 @@ extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t 
 // ------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------
-// the uniform field h (0 without), or NaN when the biases differ from site to site
-static double uniform_bias(const double *biases, size_t nvars)
+// the uniform field h (0 without); fields of one size and both signs (h_i = +-h): |h| and *signs = true;
+// NaN when the biases differ from site to site in any other way
+static double uniform_bias(const double *biases, size_t nvars, bool *signs)
 {
+    *signs = false;
     if (!biases) return 0.0;
-    for (size_t i = 1; i < nvars; i++)
-        if (biases[i] != biases[0]) return std::numeric_limits<double>::quiet_NaN();
-    return biases[0];
+    bool equal = true, same_size = true;
+    for (size_t i = 1; i < nvars; i++) {
+        equal &= biases[i] == biases[0];
+        same_size &= std::fabs(biases[i]) == std::fabs(biases[0]);
+    }
+    if (equal) return biases[0];
+    if (!same_size) return std::numeric_limits<double>::quiet_NaN();
+    *signs = true;
+    return std::fabs(biases[0]);
 }
 
-// Periodic and field-free: the two-class kernels of lattice_kernels.hpp.  A uniform field |h| <= 2|J| on a periodic
-// lattice, or open boundaries without a field: the multi-class kernels (whole quads per row needed).  Anything else
-// (site-dependent biases, a field on an open lattice, |h| > 2|J|): the general path.
-static bool lattice_fast_path_ok(const Lattice2D &L, double h)
+// Periodic and field-free: the two-class kernels of lattice_kernels.hpp.  A field |h| <= 2|J| (uniform, or +-h from
+// site to site) on a periodic lattice, open boundaries without a field or with a field |h| <= |J|, anisotropic couplings
+// (periodic, no field): the multi-class kernels (whole quads per row needed).  Anything else (other site-dependent
+// biases, larger fields, anisotropy with a field or open boundaries): the general path.
+static bool lattice_fast_path_ok(const Lattice2D &L, double h, bool field_signs)
 {
     if (!L.ok || L.W % 64 != 0) return false;
     if (std::isnan(h)) return false;
     const bool open = L.open_x || L.open_y, aniso = L.jabs != L.jabs_y;
-    if (int(open) + int(h != 0.0) + int(aniso) > 1) return false; // one generalisation at a time
+    if (aniso && (open || h != 0.0)) return false; // anisotropic couplings: periodic and field-free only
+    if (field_signs && uint64_t(L.W) * uint64_t(L.H) >= (uint64_t(1) << 31)) return false; // two 32-bit counters in one word
     if (h != 0.0 && !(std::fabs(h) <= 2.0 * L.jabs)) return false;
+    // a boundary site with one more unsatisfied than satisfied bond (m = -1) must still flip outright: |h| <= |J| there
+    if (open && h != 0.0 && !(std::fabs(h) <= L.jabs)) return false;
     if ((open || h != 0.0 || aniso) && (L.W / 64) % 4 != 0) return false;
     if (aniso && uint64_t(L.W) * uint64_t(L.H) >= (uint64_t(1) << 32)) return false; // two 32-bit bond counters in one word
     const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
@@ -465,13 +486,14 @@ static bool lattice_fast_path_ok(const Lattice2D &L, double h)
     return wpp % 4 == 0 && 2 * wpp * sizeof(uint32_t) < (uint64_t(1) << 31);
 }
 
-static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h)
+static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h, const double *biases, bool field_signs)
 {
     g->kind = ISINGMC_KIND_LATTICE2D;
-    g->mc_mode = h != 0.0 ? MC_FIELD : (L.open_x || L.open_y) ? MC_OPEN : L.jabs != L.jabs_y ? MC_ANISO : MC_NONE;
+    const bool open = L.open_x || L.open_y;
+    g->mc_mode = h != 0.0 ? (open ? MC_FIELD_OPEN : MC_FIELD) : open ? MC_OPEN : L.jabs != L.jabs_y ? MC_ANISO : MC_NONE;
     g->jabs_y = L.jabs_y;
-    g->field = h;
-    g->open = McOpen{uint32_t(L.open_x), uint32_t(L.open_y)};
+    g->field = h; // signed for a uniform field, |h| with sign planes
+    g->open = McOpen{uint32_t(L.open_x), uint32_t(L.open_y), (!field_signs && h < 0.0) ? 0xFFFFFFFFu : 0u};
     LatGeom &G = g->geom;
     G.W = L.W;
     G.H = L.H;
@@ -517,6 +539,18 @@ static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h)
         const uint32_t *d = nullptr;
         TRY(graph_upload(g, &d, jneg));
         g->d_jneg = const_cast<uint32_t *>(d);
+    }
+    if (field_signs) { // bit set where h_i < 0, each colour's compact layout
+        std::vector<uint32_t> fneg(size_t(2) * G.wpp, 0u);
+        for (uint32_t c = 0; c < 2; c++)
+            for (uint32_t y = 0; y < G.H; y++) {
+                const uint32_t o = (y + c) & 1;
+                for (uint32_t i = 0; i < G.W / 2; i++)
+                    if (biases[size_t(y) * G.W + 2 * i + o] < 0.0) fneg[size_t(c) * G.wpp + size_t(y) * G.wpr + (i >> 5)] |= 1u << (i & 31);
+            }
+        const uint32_t *d = nullptr;
+        TRY(graph_upload(g, &d, fneg));
+        g->d_fneg = const_cast<uint32_t *>(d);
     }
     return ISINGMC_OK;
 }
@@ -679,9 +713,10 @@ extern "C" int isingmc_graph_create(const uint64_t *ea, const uint64_t *eb, cons
     g->n_edges = n_edges;
     g->has_bias = has_bias;
     Lattice2D L;
-    const double h = has_bias ? uniform_bias(biases, nvars) : 0.0;
+    bool field_signs = false;
+    const double h = has_bias ? uniform_bias(biases, nvars, &field_signs) : 0.0;
     if (!(flags & ISINGMC_FLAG_FORCE_GENERAL) && !std::isnan(h)) L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    if (lattice_fast_path_ok(L, h)) TRY(build_lattice(g.get(), L, h));
+    if (lattice_fast_path_ok(L, h, field_signs)) TRY(build_lattice(g.get(), L, h, biases, field_signs));
     else TRY(build_general(g.get(), ea, eb, ej, n_edges, nvars, biases));
     *graph_out = g.release();
     return ISINGMC_OK;
@@ -705,6 +740,7 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
         info->field = g->field;
         info->open_x = int32_t(g->open.open_x);
         info->open_y = int32_t(g->open.open_y);
+        info->field_signs = g->d_fneg ? 1 : 0;
     }
     info->n_colours = g->n_colours;
     info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
@@ -1252,9 +1288,11 @@ static void launch_lat_measure(isingmc_states *s, unsigned long long *out, size_
                                           g->jneg_uniform, out + r0 * out_stride, out_stride);
             continue;
         }
-        if (g->mc_mode == MC_OPEN) { // the bonds across the open boundary do not exist: they must not count as satisfied
+        if (g->mc_mode == MC_OPEN || g->mc_mode == MC_FIELD_OPEN || g->d_fneg) {
+            // the bonds across an open boundary do not exist: they must not count as satisfied; with field-sign planes the
+            // spins along their site's field are counted too
             (void)mc_launch_measure_open(PMJ, dim3(blocks, unsigned(n)), s->stream, s->d_state + r0 * g->state_words, g->geom, g->d_jneg,
-                                         g->jneg_uniform, g->open, out + r0 * out_stride, out_stride);
+                                         g->jneg_uniform, g->open, g->d_fneg, out + r0 * out_stride, out_stride);
             continue;
         }
         hipLaunchKernelGGL((lat_measure_kernel<VEC, PMJ>), dim3(blocks, unsigned(n)), dim3(256), 0, s->stream,
@@ -1643,7 +1681,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                         const size_t n = std::min(MAX_GRID_Y, R - r0);
                         const hipError_t err = mc_launch_sweep(g->mc_mode, !g->uniform_sign, lat_grid(g, g->geom.nquads, n), s->stream,
                                                                s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
-                                                               s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open);
+                                                               s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg);
                         if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
                     }
                 if (rc != ISINGMC_OK) break;

@@ -6,23 +6,33 @@ namespace isingmc {
 template <int MODE>
 static void launch_mode(bool pmj, bool uni, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour, uint64_t t,
                         const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica, const uint32_t *jneg,
-                        uint32_t jneg_uniform, McOpen open)
+                        uint32_t jneg_uniform, McOpen open, const uint32_t *fneg)
 {
     const auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open, fneg);
     };
-    if (uni) { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, true>); else launch(lat_mc_sweep_kernel<MODE, false, true>); }
-    else { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, false>); else launch(lat_mc_sweep_kernel<MODE, false, false>); }
+    if constexpr (MODE == MC_FIELD || MODE == MC_FIELD_OPEN) {
+        if (fneg) {
+            if (uni) { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, true, true>); else launch(lat_mc_sweep_kernel<MODE, false, true, true>); }
+            else { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, false, true>); else launch(lat_mc_sweep_kernel<MODE, false, false, true>); }
+            return;
+        }
+    }
+    if (uni) { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, true, false>); else launch(lat_mc_sweep_kernel<MODE, false, true, false>); }
+    else { if (pmj) launch(lat_mc_sweep_kernel<MODE, true, false, false>); else launch(lat_mc_sweep_kernel<MODE, false, false, false>); }
 }
 
 hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
                            uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
-                           const uint32_t *jneg, uint32_t jneg_uniform, McOpen open)
+                           const uint32_t *jneg, uint32_t jneg_uniform, McOpen open, const uint32_t *fneg)
 {
     const bool uni = g.cols_log2 >= 0; // the 2^k mapping of the streaming kernels applies (build_lattice)
-    if (mode == MC_FIELD) launch_mode<MC_FIELD>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
-    else if (mode == MC_ANISO) launch_mode<MC_ANISO>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
-    else launch_mode<MC_OPEN>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open);
+#define MC_LAUNCH(M) launch_mode<M>(pmj, uni, grid, stream, state, g, colour, t, keys, thr_uniform, thr_replica, jneg, jneg_uniform, open, fneg)
+    if (mode == MC_FIELD) MC_LAUNCH(MC_FIELD);
+    else if (mode == MC_ANISO) MC_LAUNCH(MC_ANISO);
+    else if (mode == MC_FIELD_OPEN) MC_LAUNCH(MC_FIELD_OPEN);
+    else MC_LAUNCH(MC_OPEN);
+#undef MC_LAUNCH
     return hipGetLastError();
 }
 
@@ -35,10 +45,10 @@ hipError_t mc_launch_measure_aniso(bool pmj, dim3 grid, hipStream_t stream, cons
 }
 
 hipError_t mc_launch_measure_open(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
-                                  uint32_t jneg_uniform, McOpen open, unsigned long long *out, size_t out_stride)
+                                  uint32_t jneg_uniform, McOpen open, const uint32_t *fneg, unsigned long long *out, size_t out_stride)
 {
-    if (pmj) hipLaunchKernelGGL(lat_mc_measure_open_kernel<true>, grid, dim3(256), 0, stream, state, g, jneg, jneg_uniform, open, out, out_stride);
-    else hipLaunchKernelGGL(lat_mc_measure_open_kernel<false>, grid, dim3(256), 0, stream, state, g, jneg, jneg_uniform, open, out, out_stride);
+    if (pmj) hipLaunchKernelGGL(lat_mc_measure_open_kernel<true>, grid, dim3(256), 0, stream, state, g, jneg, jneg_uniform, open, fneg, out, out_stride);
+    else hipLaunchKernelGGL(lat_mc_measure_open_kernel<false>, grid, dim3(256), 0, stream, state, g, jneg, jneg_uniform, open, fneg, out, out_stride);
     return hipGetLastError();
 }
 

@@ -31,6 +31,23 @@ __device__ __forceinline__ void mc_classes(const uint32_t own, const uint32_t a0
         mask[0] = e2 & ~own; mask[1] = e2 & own;
         mask[2] = e3 & ~own; mask[3] = e3 & own;
         mask[4] = e4 & ~own; mask[5] = e4 & own;
+    } else if constexpr (MODE == MC_FIELD_OPEN) {
+        // `own` is sigma here (spin bit ^ field-sign bit); sat / unsat counted over the bonds that exist
+        const uint32_t s0 = a0 & p_up, s1 = a1 & p_dn, s2 = a2, s3 = a3 & p_si;
+        const uint32_t u0 = ~a0 & p_up, u1 = ~a1 & p_dn, u2 = ~a2, u3 = ~a3 & p_si;
+        const uint32_t s01 = s0 ^ s1, c01 = s0 & s1, s23 = s2 ^ s3, c23 = s2 & s3;
+        const uint32_t k0 = s01 ^ s23, k1 = c01 ^ c23 ^ (s01 & s23), e4 = c01 & c23;
+        const uint32_t e1 = k0 & ~k1, e2 = k1 & ~k0, e3 = k1 & k0;
+        const uint32_t us01 = u0 ^ u1, uc01 = u0 & u1, us23 = u2 ^ u3, uc23 = u2 & u3;
+        const uint32_t ub0 = us01 ^ us23, ub1 = uc01 ^ uc23 ^ (us01 & us23);
+        const uint32_t none = ~(u0 | u1 | u2 | u3), one = ub0 & ~ub1, two = ub1 & ~ub0;
+        const uint32_t m1 = e2 & one, m2 = (e3 & one) | (e2 & none), m3 = e3 & none, m4 = e4;
+        const uint32_t m0 = (e2 & two) | (e1 & one);
+        mask[0] = m1 & ~own; mask[1] = m1 & own;
+        mask[2] = m2 & ~own; mask[3] = m2 & own;
+        mask[4] = m3 & ~own; mask[5] = m3 & own;
+        mask[6] = m4 & ~own; mask[7] = m4 & own;
+        mask[8] = m0 & own;
     } else if constexpr (MODE == MC_ANISO) {
         // a0 = up, a1 = down (vertical, |Jy|); a2 = centre, a3 = side (horizontal, |Jx|)
         const uint32_t kx2 = a2 & a3, kx1 = a2 ^ a3, kx0 = ~(a2 | a3), ky2 = a0 & a1, ky1 = a0 ^ a1, ky0 = ~(a0 | a1);
@@ -39,7 +56,6 @@ __device__ __forceinline__ void mc_classes(const uint32_t own, const uint32_t a0
         mask[2] = kx1 & ky2;
         mask[3] = kx2 & ky0;
         mask[4] = kx0 & ky2;
-        mask[5] = 0;
     } else {
         // a0 = up, a1 = down, a2 = centre (always exists), a3 = side
         const uint32_t s0 = a0 & p_up, s1 = a1 & p_dn, s2 = a2, s3 = a3 & p_si;
@@ -52,14 +68,13 @@ __device__ __forceinline__ void mc_classes(const uint32_t own, const uint32_t a0
         mask[1] = (e3 & one) | (e2 & none); // m = 2: the bulk's k = 3, or a corner with both bonds satisfied
         mask[2] = e3 & none;                // m = 3: a boundary site with all three bonds satisfied
         mask[3] = e4;                       // m = 4
-        mask[4] = 0;
-        mask[5] = 0;
     }
 }
 
 template <int MODE>
 struct McInfo {
-    static constexpr int NC = MODE == MC_FIELD ? 6 : MODE == MC_ANISO ? 5 : 4;
+    static constexpr int NC = MODE == MC_FIELD_OPEN ? 9 : MODE == MC_FIELD ? 6 : MODE == MC_ANISO ? 5 : 4;
+    static constexpr bool FIELD = MODE == MC_FIELD || MODE == MC_FIELD_OPEN, OPEN = MODE == MC_OPEN || MODE == MC_FIELD_OPEN;
 };
 
 // presence masks of word w (global word index in the plane's row y, first word xw + q) for open boundaries
@@ -81,19 +96,20 @@ __device__ __forceinline__ void mc_presence(const LatGeom &g, const McOpen open,
 
 // UNI: the division-free, wave-uniform thread -> quad mapping of the streaming kernels (load_quad_uni; the host
 // passes it when g.cols_log2 >= 0); else thread_to_quad / load_quad.  Same quads either way.
-template <int MODE, bool PMJ, bool UNI>
+// FS: field-sign planes (fneg), for the FIELD modes only
+template <int MODE, bool PMJ, bool UNI, bool FS>
 __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint32_t colour, const uint64_t t, const uint2 *__restrict__ keys,
     const LatThrMC thr_uniform, const LatThrMC *__restrict__ thr_replica, const uint32_t *__restrict__ jneg,
-    const uint32_t jneg_uniform, const McOpen open)
+    const uint32_t jneg_uniform, const McOpen open, const uint32_t *__restrict__ fneg)
 {
     constexpr int NC = McInfo<MODE>::NC;
     const uint32_t r = blockIdx.y;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     // per-replica thresholds are wave-uniform: scalar loads
     const LatThrMC *tp = thr_replica ? thr_replica + r : &thr_uniform;
-    __shared__ uint32_t lo_tab[8]; // low threshold words by class, for the tie stage (one replica per workgroup)
-    if (threadIdx.x < 8) lo_tab[threadIdx.x] = threadIdx.x < uint32_t(NC) ? tp->lo[threadIdx.x] : 0u;
+    __shared__ uint32_t lo_tab[16]; // low threshold words by class, for the tie stage (one replica per workgroup)
+    if (threadIdx.x < 16) lo_tab[threadIdx.x] = threadIdx.x < uint32_t(NC) ? tp->lo[threadIdx.x] : 0u;
     __syncthreads();
     if (gid >= g.nquads) return;
     uint32_t *mine = state + size_t(r) * 2 * g.wpp;
@@ -140,8 +156,13 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
             bond_masks<false>(own[q], n, q, nullptr, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
         }
         uint32_t p_up = 0xFFFFFFFFu, p_dn = 0xFFFFFFFFu, p_si = 0xFFFFFFFFu;
-        if constexpr (MODE == MC_OPEN) mc_presence(g, open, colour, qy, qxw + q, p_up, p_dn, p_si);
-        mc_classes<MODE>(own[q], a0, a1, a2, a3, p_up, p_dn, p_si, m6);
+        if constexpr (McInfo<MODE>::OPEN) mc_presence(g, open, colour, qy, qxw + q, p_up, p_dn, p_si);
+        uint32_t sigma = own[q]; // the spin bit, or spin x sign of the site's field
+        if constexpr (McInfo<MODE>::FIELD) {
+            if constexpr (FS) sigma ^= fneg[size_t(colour) * g.wpp + widx[q]];
+            else if constexpr (MODE == MC_FIELD_OPEN) sigma ^= open.fneg_uniform;
+        }
+        mc_classes<MODE>(sigma, a0, a1, a2, a3, p_up, p_dn, p_si, m6);
         und[q] = 0;
         lt[q] = 0;
 #pragma unroll
@@ -187,15 +208,16 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
         for (int q = 0; q < 4; q++) {
             uint32_t m = und[q];
             if (!m) continue;
-            uint32_t k0 = mask[q][1] | mask[q][3], k1 = mask[q][2] | mask[q][3], k2 = 0;
+            uint32_t k0 = mask[q][1] | mask[q][3], k1 = mask[q][2] | mask[q][3], k2 = 0, k3 = 0;
             if constexpr (NC > 4) { k2 = mask[q][4]; }
             if constexpr (NC > 5) { k0 |= mask[q][5]; k2 |= mask[q][5]; }
+            if constexpr (NC > 8) { k1 |= mask[q][6] | mask[q][7]; k2 |= mask[q][6] | mask[q][7]; k0 |= mask[q][7]; k3 = mask[q][8]; }
             while (m) {
                 const uint32_t b = __ffs(m) - 1;
                 m &= m - 1;
                 if (nres != 0 && (nres & 3u) == 0)
                     w = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
-                const uint32_t idx = ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2);
+                const uint32_t idx = ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2) | (((k3 >> b) & 1u) << 3);
                 const uint32_t lo_c = lo_tab[idx];
                 if (sel4(w, nres & 3u) < lo_c) acc[q] |= 1u << b;
                 nres++;
@@ -261,11 +283,11 @@ __global__ __launch_bounds__(256) void lat_mc_measure_aniso_kernel(
 template <bool PMJ>
 __global__ __launch_bounds__(256) void lat_mc_measure_open_kernel(
     const uint32_t *__restrict__ state, const LatGeom g, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform, const McOpen open,
-    unsigned long long *__restrict__ out, const size_t out_stride)
+    const uint32_t *__restrict__ fneg, unsigned long long *__restrict__ out, const size_t out_stride)
 {
-    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t red[3][4];
     const uint32_t r = blockIdx.y;
-    uint32_t sat = 0, up = 0;
+    uint32_t sat = 0, up = 0, along = 0; // along: spins pointing along their site's field (field-sign planes only)
     const uint32_t *p0 = state + size_t(r) * 2 * g.wpp;
     for (uint32_t i = 0; i < MEASURE_QUADS_PER_THREAD; i++) {
         const uint32_t gid = (blockIdx.x * MEASURE_QUADS_PER_THREAD + i) * 256 + threadIdx.x;
@@ -281,20 +303,25 @@ __global__ __launch_bounds__(256) void lat_mc_measure_open_kernel(
             mc_presence(g, open, 0, qy, qxw + q, p_up, p_dn, p_si);
             sat += __popc(a0 & p_up) + __popc(a1 & p_dn) + __popc(a2) + __popc(a3 & p_si);
             up += __popc(own[q]) + __popc(n.ce[q]);
+            if (fneg) along += __popc(own[q] ^ fneg[widx[q]]) + __popc(n.ce[q] ^ fneg[g.wpp + widx[q]]); // the centre word: same index, colour 1
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sat += __shfl_xor(sat, off);
         up += __shfl_xor(up, off);
+        along += __shfl_xor(along, off);
     }
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = sat;
         red[1][threadIdx.x >> 6] = up;
+        red[2][threadIdx.x >> 6] = along;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(out + size_t(r) * out_stride, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        const unsigned long long s4 = (unsigned long long)red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const unsigned long long a4 = (unsigned long long)red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        atomicAdd(out + size_t(r) * out_stride, s4 | (a4 << 32)); // fewer than 2^31 spins with sign planes: the halves cannot carry
         atomicAdd(out + size_t(r) * out_stride + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
 }

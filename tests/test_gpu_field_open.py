@@ -110,10 +110,68 @@ def test_open_boundaries_bit_exact(capi, oracle, exact, W, H, open_x, open_y, gl
     _check(capi, oracle, g, lat, a, b, j, W * H, None, 5, np.array([0.0, 0.3, 0.4407, 1.2, 3.0]))
 
 
-def test_open_lattice_with_a_field_or_a_missing_interior_bond_is_general(capi, exact):
+@pytest.mark.parametrize("W,H", [(256, 16), (512, 32)])
+@pytest.mark.parametrize("open_x,open_y", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("h", [0.3, -0.75, 1.0])
+@pytest.mark.parametrize("glass", [False, True])
+def test_field_on_an_open_lattice_bit_exact(capi, oracle, exact, W, H, open_x, open_y, h, glass):
+    """Open boundaries AND a uniform field |h| <= |J|: nine classes (m = sat - unsat in 0..4, spin along / against the field)."""
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(W) if glass else None, open_x, open_y)
+    a, b, j = ea[keep], eb[keep], ej[keep]
+    biases = np.full(W * H, h)
+    g = capi.Graph(a, b, j, nvars=W * H, biases=biases)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == 4 and g.info.field == h and not g.info.field_signs
+    kw = dict(field=h, open_x=open_x, open_y=open_y)
+    lat = (oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), **kw) if glass
+           else oracle.Lat(W, H, 1.0, 0, **kw))
+    _check(capi, oracle, g, lat, a, b, j, W * H, biases, 5, np.array([0.0, 0.3, 0.4407, 1.2, 3.0]))
+
+
+@pytest.mark.parametrize("W,H", [(256, 16), (512, 32)])
+@pytest.mark.parametrize("open_x,open_y", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("glass", [False, True])
+def test_random_field_signs_bit_exact(capi, oracle, exact, W, H, open_x, open_y, glass):
+    """Biases of one size and both signs (the bimodal random-field model, h_i = +-h): sign planes turn the spin bit into
+    "along the site's field"; periodic (six classes) and open (nine); energy from the packed third counter."""
+    h = 0.8
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(W) if glass else None, open_x, open_y)
+    a, b, j = ea[keep], eb[keep], ej[keep]
+    rng = np.random.default_rng(H)
+    biases = h * rng.choice([-1.0, 1.0], W * H)
+    g = capi.Graph(a, b, j, nvars=W * H, biases=biases)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == (4 if open_x or open_y else 1)
+    assert g.info.field == h and g.info.field_signs
+    kw = dict(field=h, open_x=open_x, open_y=open_y, field_neg=(biases < 0).astype(np.uint8))
+    lat = (oracle.Lat(W, H, 1.0, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), **kw) if glass
+           else oracle.Lat(W, H, 1.0, 0, **kw))
+    _check(capi, oracle, g, lat, a, b, j, W * H, biases, 5, np.array([0.0, 0.3, 0.4407, 1.2, 3.0]))
+    # per-replica betas on the same graph
+    st = capi.States(g, SEEDS)
+    betas = [0.25, 0.9, -0.2]
+    st.set_betas(betas)
+    st.do_time_steps(4)
+    for r, s in enumerate(SEEDS):
+        ref = lat.init(s)
+        for t in range(4):
+            lat.sweep(ref, s, t, betas[r])
+        np.testing.assert_array_equal(st.packed()[r], ref)
+        assert st.energies()[r] == lat.energy_mag(ref)[0]
+
+
+def test_fields_the_multi_class_kernels_cannot_take_are_general(capi, exact):
     W, H = 256, 16
     ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, None, True, False)
-    assert capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=np.full(W * H, 0.2)).kind == capi.KIND_GENERAL
+    a, b, j = ea[keep], eb[keep], ej[keep]
+    assert capi.Graph(a, b, j, nvars=W * H, biases=np.full(W * H, 1.2)).kind == capi.KIND_GENERAL      # |h| > |J| on an open lattice
+    bb = np.full(W * H, 0.5); bb[7] = -0.25                                                            # two sizes
+    assert capi.Graph(a, b, j, nvars=W * H, biases=bb).kind == capi.KIND_GENERAL
+    bz = np.full(W * H, 0.5); bz[9] = 0.0                                                              # a site without a field
+    assert capi.Graph(ea, eb, ej, biases=bz).kind == capi.KIND_GENERAL
+
+
+def test_open_lattice_with_a_missing_interior_bond_is_general(capi, exact):
+    W, H = 256, 16
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, None, True, False)
     k2 = keep.copy(); k2[np.flatnonzero(keep)[7]] = False             # one interior bond gone: not a lattice
     assert not capi.recognise_lattice2d(ea[k2], eb[k2], ej[k2], W * H)["is_lattice"]
     k3 = keep.copy(); k3[np.flatnonzero(~keep)[0]] = True             # one wrap-around bond present, the others not

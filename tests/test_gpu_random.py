@@ -134,10 +134,11 @@ def test_random_strip_lattices(capi, oracle, exact, wq, rows, pm, R, T, beta, nw
             os.environ.pop(k, None)
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=40, **COMMON)
 @given(wq=st.sampled_from([4, 8, 12]), H=st.sampled_from([4, 6, 16, 34]), pm=st.booleans(), R=st.integers(1, 4), T=st.integers(0, 5),
        beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0, -0.3]), jabs=st.sampled_from([1.0, 0.3]),
-       mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy", "aniso_x", "aniso_y"]),
+       mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy", "aniso_x", "aniso_y", "open_x_field",
+                             "open_xy_field-", "signs", "open_y_signs"]),
        seed=st.integers(0, 2 ** 64 - 1))
 def test_random_field_and_open_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, mode, seed):
     """Multi-class checkerboard kernels on random geometries, couplings, fields, boundary conditions and anisotropies."""
@@ -147,16 +148,23 @@ def test_random_field_and_open_lattices(capi, oracle, exact, wq, H, pm, R, T, be
     if jy is not None:
         ej = ej.copy()
         ej[1::2] *= jy / jabs
-    h = {"field+": 0.37 * jabs, "field-": -1.3 * jabs, "field_max": 2.0 * jabs}.get(mode, 0.0)
-    ox, oy = mode in ("open_x", "open_xy"), mode in ("open_y", "open_xy")
+    h = {"field+": 0.37 * jabs, "field-": -1.3 * jabs, "field_max": 2.0 * jabs, "open_x_field": 0.6 * jabs, "open_xy_field-": -1.0 * jabs,
+         "signs": 1.7 * jabs, "open_y_signs": 0.45 * jabs}.get(mode, 0.0)
+    ox, oy = mode.startswith(("open_x", "open_xy")), mode.startswith(("open_y", "open_xy"))
+    signs = mode.endswith("signs")                                     # fields +-h from site to site
     keep = np.ones(len(ea), dtype=bool)
     if ox:
         keep &= ~((ea % W == W - 1) & (eb % W == 0))
     if oy:
         keep &= ~((ea // W == H - 1) & (eb // W == 0))
-    graph = capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=np.full(W * H, h) if h else None)
-    assert graph.kind == capi.KIND_LATTICE2D and graph.info.fast_path == (1 if h else 3 if jy is not None else 2)
-    kw = dict(field=h, open_x=ox, open_y=oy, jabs_y=jy)
+    biases = np.full(W * H, h) if h else None
+    if signs:
+        biases = h * np.random.default_rng(seed % 2 ** 31).choice([-1.0, 1.0], W * H)
+        biases[:2] = [h, -h]                                           # both signs for sure
+    graph = capi.Graph(ea[keep], eb[keep], ej[keep], nvars=W * H, biases=biases)
+    assert graph.kind == capi.KIND_LATTICE2D
+    assert graph.info.fast_path == ((4 if ox or oy else 1) if h else 3 if jy is not None else 2) and bool(graph.info.field_signs) == signs
+    kw = dict(field=h, open_x=ox, open_y=oy, jabs_y=jy, field_neg=(biases < 0).astype(np.uint8) if signs else None)
     lat = (oracle.Lat(W, H, jabs, 0, (ej[0::2] > 0).astype(np.uint8), (ej[1::2] > 0).astype(np.uint8), **kw) if pm
            else oracle.Lat(W, H, jabs, 0, **kw))
     seeds = capi.make_seeds(seed, R)

@@ -20,6 +20,8 @@ cases = [("periodic, h = 0", dict(), R, steps),
          ("uniform field h = 0.25", dict(biases=np.full(N, 0.25)), R, steps),
          ("open boundaries (x and y)", dict(keep=open_keep), R, steps),
          ("anisotropic |Jy| = 0.5 |Jx|", dict(jy=0.5), R, steps),
+         ("open boundaries + field h = 0.25", dict(keep=open_keep, biases=np.full(N, 0.25)), R, steps),
+         ("random field h_i = +-0.5", dict(biases=0.5 * np.random.default_rng(5).choice([-1.0, 1.0], N)), R, steps),
          ("uniform field h = 0.25, general path", dict(biases=np.full(N, 0.25), force_general=True), 16, 3)]
 for name, kw, reps, T in cases:
     keep = kw.pop("keep", None)
