@@ -178,15 +178,22 @@ def test_open_lattice_with_a_missing_interior_bond_is_general(capi, exact):
     assert not capi.recognise_lattice2d(ea[k3], eb[k3], ej[k3], W * H)["is_lattice"]
 
 
-def test_field_lattice_equilibrium_against_the_general_path(capi, exact):
-    """Independent check of the field kernel's physics: the thread-per-site CSR path (f64 local fields, other update order
-    within a colour class, other random numbers) samples the same Boltzmann distribution."""
+@pytest.mark.parametrize("mode", ["field", "open", "open_field", "field_signs", "open_field_signs", "aniso"])
+def test_multi_class_kernels_equilibrium_against_the_general_path(capi, exact, mode):
+    """Independent check of the multi-class kernels' physics: the thread-per-site CSR path (f64 local fields, other update
+    order within a colour class, other random numbers; itself checked against exact enumeration) samples the same
+    Boltzmann distribution -- two-sample z-test on <E> and <M> over 48 replicas each."""
     W, H, h, beta, R = 256, 16, 0.3, 0.35, 48
-    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
-    biases = np.full(W * H, h)
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, None, mode.startswith("open"), mode.startswith("open"))
+    ea, eb, ej = ea[keep], eb[keep], ej[keep].copy()
+    biases = np.full(W * H, h) if "field" in mode else None
+    if mode.endswith("signs"):
+        biases = h * np.random.default_rng(12).choice([-1.0, 1.0], W * H)
+    if mode == "aniso":
+        ej[1::2] *= 0.6
     obs = []
     for force in (False, True):
-        g = capi.Graph(ea, eb, ej, biases=biases, force_general=force)
+        g = capi.Graph(ea, eb, ej, nvars=W * H, biases=biases, force_general=force)
         assert (g.kind == capi.KIND_GENERAL) == force
         st = capi.States(g, capi.make_seeds(3 + force, R))
         st.do_time_steps(300, beta)
@@ -195,7 +202,8 @@ def test_field_lattice_equilibrium_against_the_general_path(capi, exact):
     for a, b, name in ((obs[0][0], obs[1][0], "E"), (obs[0][1], obs[1][1], "M")):
         z = (a.mean() - b.mean()) / math.sqrt(a.var(ddof=1) / R + b.var(ddof=1) / R)
         assert abs(z) < 4.5, (name, z, a.mean(), b.mean())
-    assert obs[0][1].mean() > 0.3 * W * H                            # the field magnetises the paramagnet
+    if mode in ("field", "open_field"):
+        assert obs[0][1].mean() > 0.3 * W * H                        # the field magnetises the paramagnet
 
 
 def test_python_api_keeps_field_and_open_lattices_on_the_fast_path(oracle, exact):
