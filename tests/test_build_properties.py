@@ -70,3 +70,23 @@ def test_packed_uniform_degree_kernels_keep_eight_waves(tmp_path):
         assert vgpr <= 64 and spill <= 4 and scratch <= 32, f"{name}: {vgpr} VGPRs, {spill} spills, {scratch} B scratch"
         if "ELb0EEE" in name:  # one coupling sign: the c5 kernels
             assert spill == 0 and scratch == 0, f"{name}: spills"
+
+
+def test_multi_class_kernels_keep_their_occupancy(tmp_path):
+    """lat_mc_sweep_kernel: the uniform-field instantiation the field benchmark runs (<FIELD, uniform sign, 2^k mapping, no
+    sign planes>) stays at 7 waves per SIMD (<= 72 VGPRs; a runtime branch on the sign-plane pointer once made it 97), the
+    open-boundary ones at 8 (<= 64), and nothing spills."""
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "mc.s"
+    src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "mc_kernels.hip")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    metas = _kernel_meta(out.read_text(), "_ZN7isingmc19lat_mc_sweep_kernel")
+    assert len(metas) == 24
+    for name, vgpr, spill, scratch in metas:
+        assert spill == 0 and scratch == 0, f"{name}: spills"
+        if "ILi1ELb0ELb1ELb0E" in name:
+            assert vgpr <= 72, f"{name}: {vgpr} VGPRs"
+        if "ILi2E" in name:
+            assert vgpr <= 65, f"{name}: {vgpr} VGPRs"
