@@ -417,6 +417,15 @@ __device__ __forceinline__ void quad_ties(const QuadState &st, const uint32_t Q,
         // the first residual call is hoisted: inside the divergent per-word loops below it would be
         // issued once per loop (up to 4x per wave) instead of once
         const uint4 rnd = first_call ? *first_call : philox4x32_10(make_uint4(c0, c1, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
+#ifdef ISINGMC_TIMING_ONLY_NO_TIE_LOOPS // diagnostic build (results are wrong): the residual call kept, the per-tie loops replaced
+        // by ONE compare per word -- the floor of any reorganisation of the loops (wave-level compaction included)
+        {
+            const uint32_t rr4[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] |= st.und[q] & (0u - uint32_t(rr4[q] < ((st.und[q] & st.eq4[q]) ? tb.lo4 : tb.lo3)));
+            return;
+        }
+#endif
         const uint32_t n_ties = __popc(st.und[0]) + __popc(st.und[1]) + __popc(st.und[2]) + __popc(st.und[3]);
         if (n_ties <= 4) {
             // all but ~0.1 % of the quads: the ties consume the four words of this one call in order.  The words
