@@ -82,8 +82,13 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k, const PhiloxVKe
     philox_round<false>(c, k);
     philox_round<false>(c, k);
     philox_round<false>(c, k);
+#ifdef ISINGMC_TIMING_ONLY_PHILOX_ROUNDS // diagnostic build (another generator: results differ): Philox4x32-R for R = 7 .. 10
+    constexpr int late_rounds = ISINGMC_TIMING_ONLY_PHILOX_ROUNDS - 3;
+#else
+    constexpr int late_rounds = 7;
+#endif
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
+    for (int r = 0; r < late_rounds; r++) {
         const uint64_t p0 = uint64_t(0xD2511F53u) * c.x;
         const uint64_t p1 = uint64_t(0xCD9E8D57u) * c.z;
         c = make_uint4(__builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c.y, vk.kx[r], 0x96), uint32_t(p1),
