@@ -1596,7 +1596,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
     // replica blocks on several streams.  Large launches (c2) keep the chip full on one stream.
     size_t want_lanes = 1;
-    if (lattice && !resident && !strip.use && !mc && !energies_per_step) {
+    if (lattice && !resident && !strip.use && !energies_per_step) { // the multi-class kernels' launches too
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
@@ -1676,13 +1676,19 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
             if (mc) {
                 const LatThrMC thr = lattice_thresholds_mc(g, beta);
+                const size_t per_lane = (R + s->n_lanes - 1) / s->n_lanes; // replica blocks on the lanes' streams, as launch_lat_sweep
                 for (uint32_t colour = 0; colour < 2 && rc == ISINGMC_OK; colour++)
-                    for (size_t r0 = 0; r0 < R; r0 += MAX_GRID_Y) {
-                        const size_t n = std::min(MAX_GRID_Y, R - r0);
-                        const hipError_t err = mc_launch_sweep(g->mc_mode, !g->uniform_sign, lat_grid(g, g->geom.nquads, n), s->stream,
-                                                               s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
-                                                               s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg);
-                        if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+                    for (size_t lane = 0; lane < s->n_lanes && rc == ISINGMC_OK; lane++) {
+                        const size_t lo = lane * per_lane, hi = std::min(R, lo + per_lane);
+                        hipStream_t stream = s->n_lanes > 1 ? s->lanes[lane] : s->stream;
+                        for (size_t r0 = lo; r0 < hi; r0 += MAX_GRID_Y) {
+                            const size_t n = std::min(MAX_GRID_Y, hi - r0);
+                            const hipError_t err = mc_launch_sweep(g->mc_mode, !g->uniform_sign, lat_grid(g, g->geom.nquads, n), stream,
+                                                                   s->d_state + r0 * g->state_words, g->geom, colour, s->t, s->d_keys + r0, thr,
+                                                                   s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open,
+                                                                   g->d_fneg);
+                            if (err != hipSuccess) { rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err)); break; }
+                        }
                     }
                 if (rc != ISINGMC_OK) break;
                 if (d_steps) { // get_energy after this timestep: a measurement pass behind the sweep (as on the general path)
