@@ -1570,7 +1570,10 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use && !mc) ? MEASURE_SLOTS : 1;
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
     const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
-    if (resident || gen_resident || strip.use) chunk = std::min<size_t>(chunk, 65536);
+    // the multi-class modes' LDS-resident kernel: same size bound; energies after every timestep keep the per-colour launches
+    const bool mc_resident = mc && !energies_per_step && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES &&
+                             g->geom.nquads <= 1024 && !resident_disabled();
+    if (resident || gen_resident || strip.use || mc_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
     long long *d_gen_mags = nullptr;
@@ -1596,7 +1599,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     // mid-size launches (a few waves per SIMD) leave the GPU idle around every kernel boundary: run the
     // replica blocks on several streams.  Large launches (c2) keep the chip full on one stream.
     size_t want_lanes = 1;
-    if (lattice && !resident && !strip.use && !energies_per_step) { // the multi-class kernels' launches too
+    if (lattice && !resident && !strip.use && !mc_resident && !energies_per_step) { // the multi-class kernels' launches too
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
         const char *e = std::getenv("ISINGMC_STREAMS");
         if (e) want_lanes = std::max(1, std::atoi(e));
@@ -1648,6 +1651,28 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
             if (final_energies && last) s->meas_fresh = true;
             if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
         }
+        if (mc_resident) {
+            DeviceScratch thr_scratch(s->stream); // freed (after a stream sync) at the end of this chunk
+            LatThrMC *d_thr_mc_steps = nullptr;
+            if (!s->has_betas) {
+                std::vector<LatThrMC> h(beta_stride ? nk : 1);
+                for (size_t k = 0; k < h.size(); k++) h[k] = lattice_thresholds_mc(g, betas[(k0 + k) * beta_stride]);
+                rc = thr_scratch.alloc(&d_thr_mc_steps, h.size());
+                if (rc != ISINGMC_OK) break;
+                HIP_TRY(hipMemcpy(d_thr_mc_steps, h.data(), h.size() * sizeof(LatThrMC), hipMemcpyHostToDevice));
+            }
+            const unsigned threads = unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            for (size_t r0 = 0; r0 < R && rc == ISINGMC_OK; r0 += 65535) {
+                const size_t n = std::min<size_t>(65535, R - r0);
+                const hipError_t err = mc_launch_resident(g->mc_mode, !g->uniform_sign, unsigned(n), threads, g->state_words * sizeof(uint32_t),
+                                                          s->stream, s->d_state + r0 * g->state_words, g->geom, s->t, uint32_t(nk), s->d_keys + r0,
+                                                          d_thr_mc_steps, uint32_t(beta_stride ? 1 : 0),
+                                                          s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg);
+                if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
+            }
+            if (rc != ISINGMC_OK) break;
+            s->t += nk;
+        }
         if (gen_resident) {
             const size_t nb = beta_stride ? nk : 1;
             if (!s->has_betas) HIP_TRY(hipMemcpyAsync(d_beta_steps, betas + k0 * beta_stride, nb * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1672,7 +1697,7 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                 HIP_TRY(hipStreamSynchronize(s->stream));
             }
         }
-        for (size_t k = k0; k < k0 + nk && !resident && !gen_resident && !strip.use; k++) {
+        for (size_t k = k0; k < k0 + nk && !resident && !gen_resident && !strip.use && !mc_resident; k++) {
             const double beta = s->has_betas ? 0.0 : betas[k * beta_stride];
             if (mc) {
                 const LatThrMC thr = lattice_thresholds_mc(g, beta);

@@ -36,6 +36,39 @@ hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, ui
     return hipGetLastError();
 }
 
+template <int MODE>
+static void launch_resident_mode(bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream, uint32_t *state,
+                                 const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys, const LatThrMC *thr_steps,
+                                 uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg, uint32_t jneg_uniform, McOpen open,
+                                 const uint32_t *fneg)
+{
+    const auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(n_replicas), dim3(threads), lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride,
+                           thr_replica, jneg, jneg_uniform, open, fneg);
+    };
+    if constexpr (MODE == MC_FIELD || MODE == MC_FIELD_OPEN) {
+        if (fneg) {
+            if (pmj) launch(lat_mc_resident_kernel<MODE, true, true>); else launch(lat_mc_resident_kernel<MODE, false, true>);
+            return;
+        }
+    }
+    if (pmj) launch(lat_mc_resident_kernel<MODE, true, false>); else launch(lat_mc_resident_kernel<MODE, false, false>);
+}
+
+hipError_t mc_launch_resident(int mode, bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream,
+                              uint32_t *state, const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys,
+                              const LatThrMC *thr_steps, uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg,
+                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg)
+{
+#define MC_RES(M) launch_resident_mode<M>(pmj, n_replicas, threads, lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride, thr_replica, jneg, jneg_uniform, open, fneg)
+    if (mode == MC_FIELD) MC_RES(MC_FIELD);
+    else if (mode == MC_ANISO) MC_RES(MC_ANISO);
+    else if (mode == MC_FIELD_OPEN) MC_RES(MC_FIELD_OPEN);
+    else MC_RES(MC_OPEN);
+#undef MC_RES
+    return hipGetLastError();
+}
+
 hipError_t mc_launch_measure_aniso(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
                                    uint32_t jneg_uniform, unsigned long long *out, size_t out_stride)
 {

@@ -122,115 +122,45 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     }
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
-    uint32_t hi[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) hi[c] = __builtin_amdgcn_readfirstlane(tp->hi[c]);
-    const uint32_t costly = __builtin_amdgcn_readfirstlane(tp->costly);
+#include "mc_quad_body.inc"
+}
 
-    uint32_t Q, qy, qxw, own[4], widx[4], vQ = 0;
-    QuadNbr n;
-    QuadSigns js;
-    if constexpr (UNI) {
-        load_quad_uni(bmem, g, colour, gid, Q, vQ, own, n);
-        qy = Q >> uint32_t(g.cols_log2);
-        qxw = (Q & ((1u << uint32_t(g.cols_log2)) - 1)) * 4;
-#pragma unroll
-        for (int q = 0; q < 4; q++) widx[q] = 4 * Q + q;
-        load_signs<PMJ>(PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, g, Q, js);
-    } else {
-        thread_to_quad<false>(g, gid, Q, qy, qxw);
-        load_signs<PMJ>(PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, g, Q, js);
-        load_quad<true, false>(mem, g, colour, Q, qy, qxw, own, n, widx);
-    }
-
-    uint32_t mask[4][NC], lt[4], und[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t a0, a1, a2, a3, m6[MC_MAX_CLASSES];
-        if constexpr (PMJ) {
-            a0 = own[q] ^ n.up[q] ^ js.w[q][0];
-            a1 = own[q] ^ n.dn[q] ^ js.w[q][1];
-            a2 = own[q] ^ n.ce[q] ^ js.w[q][2];
-            a3 = own[q] ^ n.si[q] ^ js.w[q][3];
-        } else {
-            bond_masks<false>(own[q], n, q, nullptr, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
-        }
-        uint32_t p_up = 0xFFFFFFFFu, p_dn = 0xFFFFFFFFu, p_si = 0xFFFFFFFFu;
-        if constexpr (McInfo<MODE>::OPEN) mc_presence(g, open, colour, qy, qxw + q, p_up, p_dn, p_si);
-        uint32_t sigma = own[q]; // the spin bit, or spin x sign of the site's field
-        if constexpr (McInfo<MODE>::FIELD) {
-            if constexpr (FS) sigma ^= fneg[size_t(colour) * g.wpp + widx[q]];
-            else if constexpr (MODE == MC_FIELD_OPEN) sigma ^= open.fneg_uniform;
-        }
-        mc_classes<MODE>(sigma, a0, a1, a2, a3, p_up, p_dn, p_si, m6);
-        und[q] = 0;
-        lt[q] = 0;
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            mask[q][c] = ((costly >> c) & 1u) ? m6[c] : 0u; // wave-uniform: a class that flips outright needs no random number
-            und[q] |= mask[q][c];
-        }
-    }
-    uint32_t acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = ~und[q]; // every spin outside the costly classes flips
-
-    const uint32_t c0 = uint32_t(t);
-#pragma unroll
-    for (int p = N_PLANES - 1; p >= 0; p--) { // least significant plane first, as quad_planes
-        const uint4 rnd = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, p)), key, vk);
-        const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-        uint32_t tbw[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if ((hi[c] >> (N_PLANES - 1 - p)) & 1u) { // scalar branch: the threshold bits are per replica
-#pragma unroll
-                for (int q = 0; q < 4; q++) tbw[q] |= mask[q][c];
+// LDS-resident variant for small lattices (both planes <= LDS_RESIDENT_MAX_BYTES): one workgroup owns one replica for
+// `timesteps` whole timesteps, with a workgroup barrier between the colours -- instead of two launches per timestep
+// (lat_resident_kernel's scheme for the multi-class modes).  Same quads, same counters: the same configurations.
+template <int MODE, bool PMJ, bool FS>
+__global__ __launch_bounds__(1024) void lat_mc_resident_kernel(
+    uint32_t *__restrict__ state, const LatGeom g, const uint64_t t0, const uint32_t timesteps, const uint2 *__restrict__ keys,
+    const LatThrMC *__restrict__ thr_steps, const uint32_t thr_stride, const LatThrMC *__restrict__ thr_replica,
+    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform, const McOpen open, const uint32_t *__restrict__ fneg)
+{
+    constexpr int NC = McInfo<MODE>::NC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t mc_planes[]; // plane 0 then plane 1
+    __shared__ uint32_t lo_tab[16];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *mine = state + size_t(r) * 2 * g.wpp;
+    for (uint32_t i = tid; i < g.wpp / 2; i += nthreads) // 2 * wpp words = wpp / 2 uint4
+        reinterpret_cast<uint4 *>(mc_planes)[i] = reinterpret_cast<const uint4 *>(mine)[i];
+    const uint2 key = keys[r];
+    const PhiloxVKeys vk = philox_vkeys(key);
+    constexpr bool UNI = false; // thread_to_quad / load_quad through the LDS pointers
+    const BufPlanes bmem{};     // not used without UNI
+    for (uint32_t k = 0; k < timesteps; k++) {
+        const LatThrMC *tp = thr_replica ? thr_replica + r : thr_steps + size_t(k) * thr_stride;
+        __syncthreads(); // the planes are loaded / the previous timestep's ties have read lo_tab
+        if (tid < 16) lo_tab[tid] = tid < uint32_t(NC) ? tp->lo[tid] : 0u;
+        __syncthreads();
+        const uint64_t t = t0 + k;
+        for (uint32_t colour = 0; colour < 2; colour++) {
+            const PtrPlanes mem{mc_planes + colour * g.wpp, mc_planes + (1 - colour) * g.wpp};
+            for (uint32_t gid = tid; gid < g.nquads; gid += nthreads) {
+#include "mc_quad_body.inc"
             }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            lt[q] = __builtin_amdgcn_bitop3_b32(rr[q], tbw[q], lt[q], 0x8E);   // (~r & tb) | (~(r ^ tb) & lt)
-            und[q] = __builtin_amdgcn_bitop3_b32(und[q], rr[q], tbw[q], 0x90); // eq & ~(r ^ tb)
+            __syncthreads();
         }
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] |= lt[q];
-#ifdef ISINGMC_TIMING_ONLY_NO_TIES // diagnostic build: what the tie stage costs (results are wrong without it)
-    if (false) {
-#else
-    if (und[0] | und[1] | und[2] | und[3]) { // ties: the n-th of the quad in (word, bit) order takes word n % 4 of call N_PLANES + n / 4
-#endif
-        uint32_t nres = 0;
-        uint4 w = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES)), key, vk);
-        // the class of a tied spin as a 3-bit index from three bit-planes per word; its threshold's low word from a
-        // table in LDS (one read instead of a select per class)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t m = und[q];
-            if (!m) continue;
-            uint32_t k0 = mask[q][1] | mask[q][3], k1 = mask[q][2] | mask[q][3], k2 = 0, k3 = 0;
-            if constexpr (NC > 4) { k2 = mask[q][4]; }
-            if constexpr (NC > 5) { k0 |= mask[q][5]; k2 |= mask[q][5]; }
-            if constexpr (NC > 8) { k1 |= mask[q][6] | mask[q][7]; k2 |= mask[q][6] | mask[q][7]; k0 |= mask[q][7]; k3 = mask[q][8]; }
-            while (m) {
-                const uint32_t b = __ffs(m) - 1;
-                m &= m - 1;
-                if (nres != 0 && (nres & 3u) == 0)
-                    w = philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, N_PLANES + (nres >> 2))), key, vk);
-                const uint32_t idx = ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2) | (((k3 >> b) & 1u) << 3);
-                const uint32_t lo_c = lo_tab[idx];
-                if (sel4(w, nres & 3u) < lo_c) acc[q] |= 1u << b;
-                nres++;
-            }
-        }
-    }
-    const uint4 out = make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]);
-    if constexpr (UNI) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{out.x, out.y, out.z, out.w}, bmem.rsrc, vQ, bmem.own_off, 0);
-    } else {
-        mem.store4(widx[0], out);
-    }
+    for (uint32_t i = tid; i < g.wpp / 2; i += nthreads)
+        reinterpret_cast<uint4 *>(mine)[i] = reinterpret_cast<const uint4 *>(mc_planes)[i];
 }
 
 // lat_measure_kernel with the satisfied horizontal and vertical bonds counted apart (they carry different |J|)

@@ -38,6 +38,12 @@ struct McOpen {
 hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, uint32_t *state, const LatGeom &g, uint32_t colour,
                            uint64_t t, const uint2 *keys, const LatThrMC &thr_uniform, const LatThrMC *thr_replica,
                            const uint32_t *jneg, uint32_t jneg_uniform, McOpen open, const uint32_t *fneg);
+// small lattices: `timesteps` whole timesteps of replicas [0, n_replicas) in one launch, the planes in LDS (lds_bytes = both
+// planes); thr_steps[k * thr_stride] = the thresholds of timestep t0 + k unless thr_replica (per replica) is given
+hipError_t mc_launch_resident(int mode, bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream,
+                              uint32_t *state, const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys,
+                              const LatThrMC *thr_steps, uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg,
+                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg);
 // MC_ANISO: out[r * stride] += satisfied horizontal bonds | satisfied vertical bonds << 32, out[r * stride + 1] += up spins
 hipError_t mc_launch_measure_aniso(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
                                    uint32_t jneg_uniform, unsigned long long *out, size_t out_stride);

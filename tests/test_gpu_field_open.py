@@ -327,3 +327,31 @@ def test_anisotropic_decoupled_chains_match_the_exact_energy(capi, exact):
     expect = -jx * math.tanh(beta * jx)
     # 16 replicas x 40 samples x 16384 bonds; chain energy variance per bond = J^2 sech^2 ~ 0.63 -> sigma ~ 2.5e-4 (correlated: x3)
     assert abs(e_bond - expect) < 2.5e-3, (e_bond, expect)
+
+
+@pytest.mark.parametrize("mode", ["field", "open", "open_field_signs", "aniso"])
+def test_multi_class_resident_kernel_equals_per_colour_launches(capi, exact, monkeypatch, mode):
+    """Small lattices: lat_mc_resident_kernel (planes in LDS, all timesteps in one launch) against the per-colour launches
+    (ISINGMC_DISABLE_RESIDENT=1) -- same spins, same energies; a beta schedule, then per-replica betas.  (The oracle
+    comparisons of this file run the resident kernel too: every do_time_steps call without per-step energies.)"""
+    W, H, R = 512, 64, 5
+    ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(3), mode.startswith("open"), mode.startswith("open"))
+    ea, eb, ej = ea[keep], eb[keep], ej[keep].copy()
+    biases = np.full(W * H, 0.4) if "field" in mode else None
+    if mode.endswith("signs"):
+        biases = 0.4 * np.random.default_rng(12).choice([-1.0, 1.0], W * H)
+    if mode == "aniso":
+        ea, eb, ej = _aniso_edges(exact, W, H, 1.0, 0.5, np.random.default_rng(3))
+    out = []
+    for disable in ("0", "1"):
+        monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", disable)
+        g = capi.Graph(ea, eb, ej, nvars=W * H, biases=biases)
+        assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path > 0
+        st = capi.States(g, capi.make_seeds(4, R))
+        st.do_time_steps(9, np.linspace(0.1, 1.0, 9))
+        mid = st.packed().copy()
+        st.set_betas(np.linspace(0.2, 0.9, R))
+        st.do_time_steps(7)
+        out.append((mid, st.packed().copy(), st.energies(), st.magnetisations()))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from pyisingmontecarlo_amd import _capi
 from tools.bench_configs import square
-for L, R in ((1024, 64), (2048, 64), (512, 256)):
+for L, R in ((1024, 64), (2048, 64), (512, 256), (256, 256), (256, 1024)):
     ea, eb, ej = square(L, L)
     g = _capi.Graph(ea, eb, ej, nvars=L * L, biases=np.full(L * L, 0.25))
     st = _capi.States(g, _capi.make_seeds(1, R))
