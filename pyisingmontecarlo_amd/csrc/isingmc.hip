@@ -1066,9 +1066,8 @@ static int pk_set_betas(isingmc_states *s)
     for (size_t k = 0; k < s->groups; k++)
         pk_fill_table(tabs.data() + k * PK_TAB_WORDS, s->g->jabs,
                       [&](uint32_t r) { return s->betas[std::min(s->R - 1, 32 * k + r)]; }); // pk_bit0 == 0 (checked by the caller)
-    if (s->d_tab) HIP_TRY(hipFree(s->d_tab));
-    s->d_tab = nullptr;
-    TRY(dev_alloc(&s->d_tab, tabs.size()));
+    if (!s->d_tab) TRY(dev_alloc(&s->d_tab, tabs.size())); // groups is fixed for the life of a packed container (no append): allocated once
+    HIP_TRY(hipStreamSynchronize(s->stream)); // no launch may still be reading the old tables
     HIP_TRY(hipMemcpy(s->d_tab, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return ISINGMC_OK;
 }
