@@ -355,3 +355,33 @@ def test_multi_class_resident_kernel_equals_per_colour_launches(capi, exact, mon
         out.append((mid, st.packed().copy(), st.energies(), st.magnetisations()))
     for a, b in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("W,H", [(4096, 8), (16384, 4), (2048, 16)])
+@pytest.mark.parametrize("mode", ["field", "open_field", "aniso"])
+def test_multi_class_streaming_kernels_at_wide_geometries(capi, oracle, exact, monkeypatch, W, H, mode):
+    """The streaming instantiations with the 2^k quad mapping at BASELINE c2's width (cols_log2 = 4), at W >= 16384 (the
+    branch of load_quad_uni in which a wave never leaves its row) and at 2048 -- lattices this small would otherwise run the
+    LDS-resident kernel, so it is switched off -- against the oracle, spin by spin."""
+    monkeypatch.setenv("ISINGMC_DISABLE_RESIDENT", "1")
+    opn = mode.startswith("open")
+    if mode == "aniso":
+        ea, eb, ej = _aniso_edges(exact, W, H, 0.7, 1.9, np.random.default_rng(W))
+        biases, kw = None, dict(jabs_y=1.9)
+        jabs = 0.7
+    else:
+        ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(W), opn, opn)
+        ea, eb, ej = ea[keep], eb[keep], ej[keep]
+        biases, kw, jabs = np.full(W * H, -0.6), dict(field=-0.6, open_x=opn, open_y=opn), 1.0
+    g = capi.Graph(ea, eb, ej, nvars=W * H, biases=biases)
+    assert g.kind == capi.KIND_LATTICE2D and g.info.fast_path == {"field": 1, "open_field": 4, "aniso": 3}[mode]
+    full = exact.square_lattice_edges(W, H, -1.0, np.random.default_rng(W))[2] if mode != "aniso" else ej
+    lat = oracle.Lat(W, H, jabs, 0, (full[0::2] > 0).astype(np.uint8), (full[1::2] > 0).astype(np.uint8), **kw)
+    st = capi.States(g, SEEDS[:2])
+    st.do_time_steps(3, 0.5)
+    for r, sd in enumerate(SEEDS[:2]):
+        ref = lat.init(sd)
+        for t in range(3):
+            lat.sweep(ref, sd, t, 0.5)
+        np.testing.assert_array_equal(st.packed()[r], ref)
+        assert st.energies()[r] == lat.energy_mag(ref)[0]
