@@ -1,8 +1,11 @@
 // Multi-class checkerboard kernels: the bit-sliced Metropolis half-sweep of lattice_kernels.hpp for recognised
-// lattices whose spins fall into more than two acceptance classes -- a uniform field (classes by satisfied bonds AND
-// spin value) or open boundaries (boundary sites have 3 or 2 bonds).  Same layout, same Philox counters, same
-// plane-by-plane comparison and tie rule as DESIGN.md S3; only the class masks differ (mc_types.hpp).  These inputs
-// took the thread-per-site CSR path before (1.8e11 attempts/s at 4096^2).
+// lattices whose spins fall into more than two acceptance classes -- a field (uniform, or +-h from site to site: classes
+// by satisfied bonds AND spin along / against the site's field), open boundaries (boundary sites have 3 or 2 bonds), both
+// at once, or anisotropic couplings (classes by satisfied horizontal AND vertical bonds).  Same layout, same Philox
+// counters, same plane-by-plane comparison and tie rule as DESIGN.md S3; only the class masks differ (mc_types.hpp).
+// These inputs took the thread-per-site CSR path before (1.8e11 attempts/s at 4096^2).  Streaming kernel
+// (one launch per colour) and LDS-resident kernel (small lattices, all timesteps of a call in one launch); the quad
+// update itself is mc_quad_body.inc.
 #pragma once
 #include "lattice_kernels.hpp"
 #include "mc_types.hpp"

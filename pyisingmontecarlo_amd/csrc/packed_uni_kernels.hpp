@@ -1,9 +1,9 @@
-// Replica-packed sweep for graphs whose real sites all have ONE degree D (3..6) and whose bonds all have ONE sign: the
-// 3-d cubic lattice of BASELINE config c5, triangular / honeycomb / random regular graphs, ferro- or antiferromagnetic.
+// Replica-packed sweep for graphs whose real sites all have ONE degree D (3..6): the 3-d cubic lattice of BASELINE
+// config c5, triangular / honeycomb / random regular graphs -- ferromagnetic, antiferromagnetic, or +-J (PMJ).
 // Same layout, same random numbers, same decisions as pk_sweep_kernel (packed_kernels.hpp) -- the oracle's engine D --
 // with everything that kernel derives per lane and per slot from the ELL entries (is the slot used, the bond's sign, the
 // degree, its parity, the class thresholds' table rows) folded into template constants and scalars:
-//   * satisfied bonds: one v_bitop3 per neighbour (s ^ n ^ negmask), counted with a carry-save adder tree
+//   * satisfied bonds: one v_bitop3 per neighbour (s ^ n ^ sign), counted with a carry-save adder tree
 //     (8 three-input instructions for 6 neighbours) instead of a serial 3-bit counter (5 per neighbour);
 //   * the costly classes k = D/2 + 1 .. D are compile-time patterns of the counter: one v_bitop3 each;
 //   * bit-plane comparison from the least significant plane up (two v_bitop3 per word and plane, lattice_kernels.hpp);
