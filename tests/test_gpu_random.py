@@ -10,6 +10,7 @@ from hypothesis import strategies as st
 
 pytestmark = pytest.mark.gpu
 COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+SCALE = int(os.environ.get("ISINGMC_HYP_SCALE", "1"))  # a longer differential campaign: ISINGMC_HYP_SCALE=20 pytest tests/test_gpu_random.py
 
 
 @st.composite
@@ -37,7 +38,7 @@ def random_graph(draw, uniform):
     return ea, eb, ej, nvars
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=25 * SCALE, **COMMON)
 @given(g=random_graph(uniform=False), R=st.integers(1, 11), T=st.integers(0, 6),
        beta=st.sampled_from([0.0, 0.05, 0.4, 1.3, 7.0, -0.2]), with_bias=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
 def test_random_general_graphs(capi, oracle, g, R, T, beta, with_bias, seed):
@@ -54,7 +55,7 @@ def test_random_general_graphs(capi, oracle, g, R, T, beta, with_bias, seed):
         assert abs(energies[r] - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=25 * SCALE, **COMMON)
 @given(g=random_graph(uniform=True), R=st.integers(1, 70), T=st.integers(0, 5),
        beta=st.sampled_from([0.0, 0.1, 0.5, 2.0, 30.0]), per_replica=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
 def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_replica, seed):
@@ -75,7 +76,7 @@ def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_repl
     assert np.allclose(states.energies(), e_ref, rtol=1e-12, atol=1e-9)
 
 
-@settings(max_examples=20, **COMMON)
+@settings(max_examples=20 * SCALE, **COMMON)
 @given(wq=st.integers(1, 6), H=st.sampled_from([2, 4, 6, 8, 12, 16, 34]), pm=st.booleans(), R=st.integers(1, 5),
        T=st.integers(0, 5), beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0]), jabs=st.sampled_from([1.0, 0.3]),
        seed=st.integers(0, 2 ** 64 - 1))
@@ -101,7 +102,7 @@ def test_random_lattices(capi, oracle, exact, wq, H, pm, R, T, beta, jabs, seed)
         assert np.array_equal(packed[r], ref)
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=25 * SCALE, **COMMON)
 @given(wq=st.sampled_from([4, 8, 16, 32]), rows=st.sampled_from([2, 4, 6, 16]), pm=st.booleans(), R=st.integers(1, 9),
        T=st.integers(2, 6), beta=st.sampled_from([0.0, 0.3, 0.4407, 1.5]), nw=st.sampled_from(["1", "4"]),
        per_step=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
@@ -134,7 +135,7 @@ def test_random_strip_lattices(capi, oracle, exact, wq, rows, pm, R, T, beta, nw
             os.environ.pop(k, None)
 
 
-@settings(max_examples=40, **COMMON)
+@settings(max_examples=40 * SCALE, **COMMON)
 @given(wq=st.sampled_from([4, 8, 12]), H=st.sampled_from([4, 6, 16, 34]), pm=st.booleans(), R=st.integers(1, 4), T=st.integers(0, 5),
        beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0, -0.3]), jabs=st.sampled_from([1.0, 0.3]),
        mode=st.sampled_from(["field+", "field-", "field_max", "open_x", "open_y", "open_xy", "aniso_x", "aniso_y", "open_x_field",
