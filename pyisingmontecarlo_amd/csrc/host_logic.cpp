@@ -273,6 +273,7 @@ uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const doub
 
 // ---- packed checkerboard planes -> one byte per spin (get_state copy-out, lattice.rs:209-211) ------------
 #include <emmintrin.h>
+#include <immintrin.h>
 namespace isingmc {
 
 // bit k of the index -> byte k of the entry
@@ -317,8 +318,35 @@ static void unpack_lattice_impl(uint32_t W, uint32_t H, const uint32_t *words, u
     if (STREAM) _mm_sfence();
 }
 
+// AVX-512BW + BMI2 hosts: the two colour words of 64 sites are interleaved into one 64-bit mask by two pdep, and
+// vpmovm2b-style (maskz_mov) turns the mask into 64 bytes -- 8 instructions per 64 sites where the table version takes ~32
+__attribute__((target("avx512f,avx512bw,bmi2"))) static void unpack_lattice_avx512(uint32_t W, uint32_t H, const uint32_t *words,
+                                                                                   uint8_t *spins, bool aligned64)
+{
+    const uint32_t wpr = W / 64;
+    const size_t wpp = size_t(H) * wpr;
+    const __m512i ones = _mm512_set1_epi8(1);
+    for (uint32_t y = 0; y < H; y++) {
+        const uint32_t *even = words + (y & 1 ? wpp : 0) + size_t(y) * wpr; // as unpack_lattice_impl
+        const uint32_t *odd = words + (y & 1 ? 0 : wpp) + size_t(y) * wpr;
+        uint8_t *out = spins + size_t(y) * W;
+        for (uint32_t xw = 0; xw < wpr; xw++) {
+            const __mmask64 m = _pdep_u64(even[xw], 0x5555555555555555ull) | _pdep_u64(odd[xw], 0xAAAAAAAAAAAAAAAAull);
+            const __m512i v = _mm512_maskz_mov_epi8(m, ones);
+            if (aligned64) _mm512_stream_si512(reinterpret_cast<__m512i *>(out + 64 * size_t(xw)), v);
+            else _mm512_storeu_si512(out + 64 * size_t(xw), v);
+        }
+    }
+    if (aligned64) _mm_sfence();
+}
+
 void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins)
 {
+    static const bool avx512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("bmi2") && !std::getenv("ISINGMC_NO_AVX512");
+    if (avx512) {
+        unpack_lattice_avx512(W, H, words, spins, (reinterpret_cast<uintptr_t>(spins) & 63u) == 0);
+        return;
+    }
     if ((reinterpret_cast<uintptr_t>(spins) & 15u) == 0) unpack_lattice_impl<true>(W, H, words, spins); // rows are multiples of 64 bytes
     else unpack_lattice_impl<false>(W, H, words, spins);
 }
