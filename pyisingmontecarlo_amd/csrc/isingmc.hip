@@ -1569,9 +1569,8 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
     const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use && !mc) ? MEASURE_SLOTS : 1;
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
     const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
-    // the multi-class modes' LDS-resident kernel: same size bound; energies after every timestep keep the per-colour launches
-    const bool mc_resident = mc && !energies_per_step && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES &&
-                             g->geom.nquads <= 1024 && !resident_disabled();
+    // the multi-class modes' LDS-resident kernel: same size bound
+    const bool mc_resident = mc && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 && !resident_disabled();
     if (resident || gen_resident || strip.use || mc_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
@@ -1666,7 +1665,8 @@ static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, s
                 const hipError_t err = mc_launch_resident(g->mc_mode, !g->uniform_sign, unsigned(n), threads, g->state_words * sizeof(uint32_t),
                                                           s->stream, s->d_state + r0 * g->state_words, g->geom, s->t, uint32_t(nk), s->d_keys + r0,
                                                           d_thr_mc_steps, uint32_t(beta_stride ? 1 : 0),
-                                                          s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg);
+                                                          s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg,
+                                                          d_steps ? d_steps + 2 * r0 : nullptr, uint32_t(R));
                 if (err != hipSuccess) rc = fail(ISINGMC_ERR_HIP, hipGetErrorString(err));
             }
             if (rc != ISINGMC_OK) break;

@@ -40,11 +40,11 @@ template <int MODE>
 static void launch_resident_mode(bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream, uint32_t *state,
                                  const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys, const LatThrMC *thr_steps,
                                  uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg, uint32_t jneg_uniform, McOpen open,
-                                 const uint32_t *fneg)
+                                 const uint32_t *fneg, unsigned long long *steps_out, uint32_t steps_replicas)
 {
     const auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(n_replicas), dim3(threads), lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride,
-                           thr_replica, jneg, jneg_uniform, open, fneg);
+                           thr_replica, jneg, jneg_uniform, open, fneg, steps_out, steps_replicas);
     };
     if constexpr (MODE == MC_FIELD || MODE == MC_FIELD_OPEN) {
         if (fneg) {
@@ -58,9 +58,10 @@ static void launch_resident_mode(bool pmj, unsigned n_replicas, unsigned threads
 hipError_t mc_launch_resident(int mode, bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream,
                               uint32_t *state, const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys,
                               const LatThrMC *thr_steps, uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg,
-                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg)
+                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg, unsigned long long *steps_out,
+                              uint32_t steps_replicas)
 {
-#define MC_RES(M) launch_resident_mode<M>(pmj, n_replicas, threads, lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride, thr_replica, jneg, jneg_uniform, open, fneg)
+#define MC_RES(M) launch_resident_mode<M>(pmj, n_replicas, threads, lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride, thr_replica, jneg, jneg_uniform, open, fneg, steps_out, steps_replicas)
     if (mode == MC_FIELD) MC_RES(MC_FIELD);
     else if (mode == MC_ANISO) MC_RES(MC_ANISO);
     else if (mode == MC_FIELD_OPEN) MC_RES(MC_FIELD_OPEN);

@@ -135,11 +135,15 @@ template <int MODE, bool PMJ, bool FS>
 __global__ __launch_bounds__(1024) void lat_mc_resident_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint64_t t0, const uint32_t timesteps, const uint2 *__restrict__ keys,
     const LatThrMC *__restrict__ thr_steps, const uint32_t thr_stride, const LatThrMC *__restrict__ thr_replica,
-    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform, const McOpen open, const uint32_t *__restrict__ fneg)
+    const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform, const McOpen open, const uint32_t *__restrict__ fneg,
+    unsigned long long *__restrict__ steps_out, const uint32_t n_replicas)
 {
+    // steps_out (optional): the counters of lat_mc_measure_open_kernel / lat_mc_measure_aniso_kernel after every timestep,
+    // [step][replica][2] (get_energy after each step, lattice.rs:454)
     constexpr int NC = McInfo<MODE>::NC;
     extern __shared__ __attribute__((aligned(16))) uint32_t mc_planes[]; // plane 0 then plane 1
     __shared__ uint32_t lo_tab[16];
+    __shared__ uint32_t red[3][16];
     const uint32_t r = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t *mine = state + size_t(r) * 2 * g.wpp;
     for (uint32_t i = tid; i < g.wpp / 2; i += nthreads) // 2 * wpp words = wpp / 2 uint4
@@ -158,6 +162,47 @@ __global__ __launch_bounds__(1024) void lat_mc_resident_kernel(
             const PtrPlanes mem{mc_planes + colour * g.wpp, mc_planes + (1 - colour) * g.wpp};
             for (uint32_t gid = tid; gid < g.nquads; gid += nthreads) {
 #include "mc_quad_body.inc"
+            }
+            __syncthreads();
+        }
+        if (steps_out) {
+            // c0 = satisfied bonds (anisotropic: the horizontal ones), c1 = up spins, c2 = the vertical satisfied bonds /
+            // the spins along their site's field (sign planes): packed into the high half of word 0 as the measure kernels do
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            for (uint32_t gid = tid; gid < g.nquads; gid += nthreads) {
+                uint32_t Q, qy, qxw, own[4], widx[4];
+                thread_to_quad<false>(g, gid, Q, qy, qxw);
+                QuadNbr n;
+                load_quad<true, false>(PtrPlanes{mc_planes, mc_planes + g.wpp}, g, 0, Q, qy, qxw, own, n, widx);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t a0, a1, a2, a3;
+                    bond_masks<PMJ>(own[q], n, q, jneg, g.wpp, widx[q], jneg_uniform, a0, a1, a2, a3);
+                    if constexpr (MODE == MC_ANISO) {
+                        c2 += __popc(a0) + __popc(a1);
+                        c0 += __popc(a2) + __popc(a3);
+                    } else {
+                        uint32_t p_up = 0xFFFFFFFFu, p_dn = 0xFFFFFFFFu, p_si = 0xFFFFFFFFu;
+                        if constexpr (McInfo<MODE>::OPEN) mc_presence(g, open, 0, qy, qxw + q, p_up, p_dn, p_si);
+                        c0 += __popc(a0 & p_up) + __popc(a1 & p_dn) + __popc(a2) + __popc(a3 & p_si);
+                        if constexpr (FS) c2 += __popc(own[q] ^ fneg[widx[q]]) + __popc(n.ce[q] ^ fneg[g.wpp + widx[q]]);
+                    }
+                    c1 += __popc(own[q]) + __popc(n.ce[q]);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                c0 += __shfl_xor(c0, off);
+                c1 += __shfl_xor(c1, off);
+                c2 += __shfl_xor(c2, off);
+            }
+            if ((tid & 63) == 0) { red[0][tid >> 6] = c0; red[1][tid >> 6] = c1; red[2][tid >> 6] = c2; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long s0 = 0, s1 = 0, s2 = 0;
+                for (uint32_t w = 0; w < (nthreads + 63) / 64; w++) { s0 += red[0][w]; s1 += red[1][w]; s2 += red[2][w]; }
+                steps_out[(size_t(k) * n_replicas + r) * 2] = s0 | (s2 << 32);
+                steps_out[(size_t(k) * n_replicas + r) * 2 + 1] = s1;
             }
             __syncthreads();
         }

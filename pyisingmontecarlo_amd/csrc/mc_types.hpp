@@ -43,7 +43,9 @@ hipError_t mc_launch_sweep(int mode, bool pmj, dim3 grid, hipStream_t stream, ui
 hipError_t mc_launch_resident(int mode, bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream,
                               uint32_t *state, const LatGeom &g, uint64_t t0, uint32_t timesteps, const uint2 *keys,
                               const LatThrMC *thr_steps, uint32_t thr_stride, const LatThrMC *thr_replica, const uint32_t *jneg,
-                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg);
+                              uint32_t jneg_uniform, McOpen open, const uint32_t *fneg, unsigned long long *steps_out,
+                              uint32_t steps_replicas);
+// (steps_out: optional, the measure kernels' two counters after every timestep, [step][steps_replicas][2])
 // MC_ANISO: out[r * stride] += satisfied horizontal bonds | satisfied vertical bonds << 32, out[r * stride + 1] += up spins
 hipError_t mc_launch_measure_aniso(bool pmj, dim3 grid, hipStream_t stream, const uint32_t *state, const LatGeom &g, const uint32_t *jneg,
                                    uint32_t jneg_uniform, unsigned long long *out, size_t out_stride);

@@ -332,8 +332,9 @@ def test_anisotropic_decoupled_chains_match_the_exact_energy(capi, exact):
 @pytest.mark.parametrize("mode", ["field", "open", "open_field_signs", "aniso"])
 def test_multi_class_resident_kernel_equals_per_colour_launches(capi, exact, monkeypatch, mode):
     """Small lattices: lat_mc_resident_kernel (planes in LDS, all timesteps in one launch) against the per-colour launches
-    (ISINGMC_DISABLE_RESIDENT=1) -- same spins, same energies; a beta schedule, then per-replica betas.  (The oracle
-    comparisons of this file run the resident kernel too: every do_time_steps call without per-step energies.)"""
+    (ISINGMC_DISABLE_RESIDENT=1) -- same spins, same energies after every timestep; beta schedules, then per-replica betas.
+    (The oracle comparisons of this file at 256 x 16 ... 1024 x 8 run the resident kernel; the per-colour launches are
+    compared with the oracle at the wide geometries and through this equality.)"""
     W, H, R = 512, 64, 5
     ea, eb, ej, keep = _open_lattice(exact, W, H, -1.0, np.random.default_rng(3), mode.startswith("open"), mode.startswith("open"))
     ea, eb, ej = ea[keep], eb[keep], ej[keep].copy()
@@ -350,9 +351,10 @@ def test_multi_class_resident_kernel_equals_per_colour_launches(capi, exact, mon
         st = capi.States(g, capi.make_seeds(4, R))
         st.do_time_steps(9, np.linspace(0.1, 1.0, 9))
         mid = st.packed().copy()
+        eps = st.do_time_steps(6, np.linspace(1.0, 0.3, 6), per_step_energies=True)   # counters inside the launch vs a measurement pass per step
         st.set_betas(np.linspace(0.2, 0.9, R))
         st.do_time_steps(7)
-        out.append((mid, st.packed().copy(), st.energies(), st.magnetisations()))
+        out.append((mid, eps, st.packed().copy(), st.energies(), st.magnetisations()))
     for a, b in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, b)
 
