@@ -1868,7 +1868,8 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
             hipLaunchKernelGGL(pk_measure_kernel, dim3(blocks, unsigned(ng)), dim3(256), 0, s->stream,
-                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(32 * ng), ppt);
+                               s->d_state + g0 * g->pk.n_pos, g->pk, counts_slot + 2 * 32 * g0, uint32_t(32 * ng), ppt,
+                               g->n_colours == 2 ? uint32_t(g->class_base[1]) : g->pk.n_pos, g->n_colours == 2 ? 2u : 1u);
         }
     } else if (g->kind == ISINGMC_KIND_LATTICE2D) {
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * R * sizeof(unsigned long long), s->stream));

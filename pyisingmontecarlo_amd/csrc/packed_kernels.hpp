@@ -230,9 +230,12 @@ __device__ __forceinline__ void bs_add(uint32_t (&S)[K], const uint32_t (&x)[K2]
 
 // pos_per_thread <= PK_MEASURE_POS_PER_THREAD: fewer positions per thread give a mid-size graph enough workgroups
 // (a thread walks its positions one after the other, each a chain of dependent loads)
+// sat_end / sat_scale: on a 2-coloured (bipartite) graph every bond joins class 0 to class 1, so the bonds are counted from
+// the class-0 positions only (sat_end = the end of class 0) and doubled (sat_scale = 2) into the same directed total -- half
+// the neighbour gathers; otherwise sat_end = n_pos, sat_scale = 1.
 __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restrict__ state, const PkGraphDev G,
                                                          unsigned long long *__restrict__ out, const uint32_t n_replicas,
-                                                         const uint32_t pos_per_thread)
+                                                         const uint32_t pos_per_thread, const uint32_t sat_end, const uint32_t sat_scale)
 {
     __shared__ uint32_t red[2][4][32];
     const uint32_t g = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -248,6 +251,9 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
             if (p >= G.n_pos) break;
             if (G.site[p] == PAD_SITE) continue;
             const uint32_t s = st[p];
+            const uint32_t up[1] = {s};
+            bs_add(U, up);
+            if (p >= sat_end) continue; // wave-uniform: class boundaries are multiples of 256
             uint32_t x[PK_MAX_DEG], n[PK_MAX_DEG];
             // (the lanes that left the loop above hold no header: the block index is the same for all lanes that remain)
             const uint2 *hdr = G.ell_hdr + size_t(__builtin_amdgcn_readfirstlane(p >> 6)) * PK_MAX_DEG;
@@ -258,8 +264,6 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
             uint32_t deg, c[3];
             pk_count(x, n, s, deg, c[0], c[1], c[2]);
             bs_add(S, c);
-            const uint32_t up[1] = {s};
-            bs_add(U, up);
         }
         // transpose: replica r's count = sum over planes i of 2^i x (lanes of this wave with bit r of plane i set)
         for (uint32_t r = 0; r < 32; r++) {
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
         unsigned long long s = 0, u = 0;
         for (int k = 0; k < 4; k++) { s += red[0][k][threadIdx.x]; u += red[1][k][threadIdx.x]; }
         if (r < n_replicas && (s | u)) {
-            atomicAdd(out + 2 * size_t(r), s);
+            atomicAdd(out + 2 * size_t(r), s * sat_scale);
             atomicAdd(out + 2 * size_t(r) + 1, u);
         }
     }
