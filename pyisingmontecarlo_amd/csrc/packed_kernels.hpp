@@ -25,17 +25,6 @@
 
 namespace isingmc {
 
-// ELL slot of position p: from the (wave-uniform) block header where the block is a translation or unused,
-// else from the table
-__device__ __forceinline__ uint32_t pk_slot(const uint2 h, const __amdgpu_buffer_rsrc_t ell_rsrc, const uint32_t slot_base,
-                                            const uint32_t p)
-{
-    const uint32_t kind = __builtin_amdgcn_readfirstlane(h.x & 3u);
-    if (kind == PK_HDR_MIXED) return __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (slot_base + p), 0, 0);
-    if (kind == PK_HDR_UNUSED) return PK_NO_NBR;
-    return (p + h.y) | (h.x & 0x80000000u);
-}
-
 // satisfied-bond count of the 32 replicas at one position, bit-sliced (c0 = LSB), from its ELL slots x[] and the
 // gathered neighbour words n[].  Fixed trip count with predication.
 __device__ __forceinline__ void pk_count(const uint32_t x[PK_MAX_DEG], const uint32_t n[PK_MAX_DEG], uint32_t s,
@@ -257,8 +246,18 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
             uint32_t x[PK_MAX_DEG], n[PK_MAX_DEG];
             // (the lanes that left the loop above hold no header: the block index is the same for all lanes that remain)
             const uint2 *hdr = G.ell_hdr + size_t(__builtin_amdgcn_readfirstlane(p >> 6)) * PK_MAX_DEG;
+            uint2 h[PK_MAX_DEG]; // the six headers first, then straight-line code with load-only branches (as pk_sweep_kernel)
 #pragma unroll
-            for (int i = 0; i < PK_MAX_DEG; i++) x[i] = pk_slot(hdr[i], ell_rsrc, uint32_t(i) * G.n_pos, p);
+            for (int i = 0; i < PK_MAX_DEG; i++) h[i] = hdr[i];
+#pragma unroll
+            for (int i = 0; i < PK_MAX_DEG; i++) {
+                const uint32_t hx = __builtin_amdgcn_readfirstlane(h[i].x), hy = __builtin_amdgcn_readfirstlane(h[i].y);
+                x[i] = (p + hy) | ((hx & 3u) == PK_HDR_UNUSED ? PK_NO_NBR : (hx & 0x80000000u));
+            }
+#pragma unroll
+            for (int i = 0; i < PK_MAX_DEG; i++)
+                if ((__builtin_amdgcn_readfirstlane(h[i].x) & 3u) == PK_HDR_MIXED)
+                    x[i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p), 0, 0);
 #pragma unroll
             for (int i = 0; i < PK_MAX_DEG; i++) n[i] = st[x[i] == PK_NO_NBR ? p : (x[i] & 0x7FFFFFFFu)];
             uint32_t deg, c[3];
