@@ -1228,7 +1228,7 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
                 static const int forced = [] { const char *e = getenv("ISINGMC_SWEEP_ITERS"); return e ? atoi(e) : 0; }();
                 const uint32_t want = forced ? uint32_t(forced) : 2u;
                 if (want > 1 && g->geom.nquads % (256 * want) == 0 &&
-                    (forced || size_t(g->geom.nquads / (256 * want)) * n >= size_t(16) * 256))
+                    (forced || size_t(g->geom.nquads / (256 * want)) * n >= size_t(8) * 256)) // >= 8 workgroups per CU left (c4: +2.6 %)
                     iters = want;
             }
             if (iters > 1)
