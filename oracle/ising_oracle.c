@@ -813,3 +813,223 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
     free(site_of);
     gen_free(&G);
 }
+
+/* ==========================================================================================
+ * E. replica-packed REAL-COUPLING engine: any real J and any site biases
+ * (lattice.rs:46-50 edge list, :104-131 set_individual_bias / set_global_bias, :186-189), graphs of
+ * degree <= 7.  Same colouring, positions, replica groups, group keys and random start as engine D.
+ * The acceptance test runs in the LOG domain on integers, so that nothing per attempt needs exp():
+ *
+ *   quantisation (once per graph)   k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
+ *                                   Jq_e = rint(J_e 2^-k), hq_i = rint(h_i 2^-k)   (int32, |X| <= ~2^30)
+ *   half energy change              X = s_i (hq_i - sum_e Jq_e s_j)                (dE = 2 X 2^k)
+ *   uniform                         u = word (b & 3) of Philox(key_g, (t_lo, p, "RJSW", ctr2(t,0,b>>2)))
+ *                                   for replica bit b of the group at position p
+ *   Lambda_q(u) ~ -log2(u / 2^32) in Q24 from the bits of (float)u: exponent field + a 2048-interval
+ *                                   table of log2(1 + m) with linear interpolation
+ *   per beta                        kappa = ln2 / (2 beta 2^k) (X units per unit of -log2 u);
+ *                                   r = max(0, ilogb(kappa) - 23), mant = floor(kappa 2^(8 - r))
+ *   accept                          iff max(X >> r, 0) <= (Lambda_q * mant) >> 32
+ *                                   (u / 2^32 < exp(-beta dE) with ~2^-23 relative resolution in beta dE)
+ *   energy                          E = 2^k (sum_bonds Jq s s - sum_i hq_i s_i) + sum of self-loop J
+ *
+ * Written spin by spin with a direct integer field sum: the HIP kernel's per-site tables, bit
+ * transposition and carry tricks are checked against this independently.
+ * ======================================================================================== */
+#define DOM_RJ_SWEEP 0x524A5357u /* "RJSW" */
+#define RJ_MAX_DEG 7
+#define RJ_LOG_INTERVALS 2048
+
+/* LT[i] ~ log2(1 + x_i) 2^24, x_i = i / 2048, i = 0 .. 2048, centred for the interpolation that uses it: the chord of
+ * the concave log2 lies below the curve by up to h^2 log2(e) / (8 (1 + x)^2) (h = 1/2048) and the interpolation rounds
+ * down, so every entry but the first carries half that gap plus half a unit: LT[i] = rint((log2(1 + x_i) + h^2 log2(e) /
+ * (16 (1 + x_i)^2)) 2^24 + 0.5).  LT[0] = 0 exactly: Lambda_q of a u that rounds to 2^32 must be 0, not negative. */
+void orc_rj_log_table(uint32_t *out)
+{
+    const double h = 1.0 / RJ_LOG_INTERVALS, LOG2E = 1.4426950408889634074;
+    out[0] = 0;
+    for (int i = 1; i <= RJ_LOG_INTERVALS; i++) {
+        const double x = (double)i * h;
+        out[i] = (uint32_t)nearbyint(ldexp(log2(1.0 + x) + h * h * LOG2E / (16.0 * (1.0 + x) * (1.0 + x)), 24) + 0.5);
+    }
+}
+
+uint32_t orc_rj_lambda(uint32_t u)
+{
+    static uint32_t LT[RJ_LOG_INTERVALS + 1];
+    static int have = 0;
+    if (!have) { orc_rj_log_table(LT); have = 1; } /* engine E runs on one thread */
+    float f = (float)u; /* round to nearest even: 24 significant bits of u */
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    uint32_t E = bits >> 23, idx = (bits >> 12) & 0x7FFu, frac = bits & 0xFFFu;
+    uint32_t val = LT[idx] + (uint32_t)(((uint64_t)(LT[idx + 1] - LT[idx]) * frac) >> 12);
+    return (159u << 24) - (E << 24) - val;
+}
+
+/* quantisation exponent k, quantised coupling per INPUT edge (0 for self-loops) and bias per site */
+void orc_rj_quantise(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                     const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+    double fmax = 0.0;
+    for (size_t i = 0; i < nvars; i++) {
+        double f = biases ? fabs(biases[i]) : 0.0;
+        for (size_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) f += fabs(A.w[e]);
+        if (f > fmax) fmax = f;
+    }
+    adj_free(&A);
+    int k = fmax > 0.0 ? ilogb(fmax) + 1 - 30 : 0;
+    if (k_out) *k_out = k;
+    for (size_t e = 0; e < n_edges && jq_out; e++)
+        jq_out[e] = ea[e] == eb[e] ? 0 : (int32_t)nearbyint(ldexp(ej[e], -k));
+    for (size_t i = 0; i < nvars && hq_out; i++)
+        hq_out[i] = biases ? (int32_t)nearbyint(ldexp(biases[i], -k)) : 0;
+}
+
+/* eligibility for this path: degree <= 7, Fmax > 0 and Fmax <= 64 x the (lower) median nonzero |coupling or bias|: the
+ * absolute rounding error 2^(k-1) of a coupling is then below 2^-25 of that median */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_rj_eligible(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                    const double *biases)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+    double fmax = 0.0;
+    size_t terms = 0, maxdeg = 0;
+    double *mags = malloc((n_edges + nvars + 1) * sizeof(double));
+    for (size_t i = 0; i < nvars; i++) {
+        double f = biases ? fabs(biases[i]) : 0.0;
+        if (f != 0.0) mags[terms++] = f;
+        for (size_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) f += fabs(A.w[e]);
+        if (f > fmax) fmax = f;
+        if (A.ptr[i + 1] - A.ptr[i] > maxdeg) maxdeg = A.ptr[i + 1] - A.ptr[i];
+    }
+    adj_free(&A);
+    for (size_t e = 0; e < n_edges; e++)
+        if (ea[e] != eb[e] && ej[e] != 0.0) mags[terms++] = fabs(ej[e]);
+    double median = 0.0;
+    if (terms) {
+        qsort(mags, terms, sizeof(double), cmp_double);
+        median = mags[(terms - 1) / 2];
+    }
+    free(mags);
+    return maxdeg <= RJ_MAX_DEG && fmax > 0.0 && fmax <= 64.0 * median;
+}
+
+void orc_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
+{
+    uint32_t shift = 31, mant = 0xFFFFFFFFu; /* beta <= 0: every attempt is accepted */
+    if (beta > 0.0) {
+        double kappa = ldexp(0.69314718055994530942 / (2.0 * beta), -k);
+        int e = kappa > 0.0 && isfinite(kappa) ? ilogb(kappa) : (kappa > 0.0 ? 2000 : -2000);
+        int r = e - 23 > 0 ? e - 23 : 0;
+        if (r <= 31) {
+            shift = (uint32_t)r;
+            mant = (uint32_t)floor(ldexp(kappa, 8 - r)); /* kappa 2^-r < 2^24 */
+        }
+    }
+    *shift_out = shift;
+    *mant_out = mant;
+}
+
+int orc_rj_accept(int32_t X, uint32_t u, uint32_t shift, uint32_t mant)
+{
+    int32_t xs = X >> shift; /* arithmetic */
+    uint32_t xpos = xs > 0 ? (uint32_t)xs : 0u;
+    uint32_t y = (uint32_t)(((uint64_t)orc_rj_lambda(u) * mant) >> 32);
+    return xpos <= y;
+}
+
+/* E = 2^k (sum_bonds Jq s s - sum_i hq s) + self-loop constant: an exact integer sum, so any order gives the same bits */
+static double rj_energy(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const int32_t *jq_edge, size_t nvars,
+                        const int32_t *hq, int k, double self_energy, const uint8_t *s)
+{
+    int64_t eq = 0;
+    for (size_t e = 0; e < n_edges; e++)
+        if (ea[e] != eb[e]) eq += (int64_t)jq_edge[e] * ((s[ea[e]] != 0) == (s[eb[e]] != 0) ? 1 : -1);
+    for (size_t i = 0; i < nvars; i++) eq -= (int64_t)hq[i] * (s[i] ? 1 : -1);
+    return ldexp((double)eq, k) + self_energy;
+}
+
+/* states: uint8[32*G][nvars] as engine D; betas per timestep, or beta_replica[R] (padding replicas of the
+ * last group then use beta_replica[R-1]) */
+void orc_rj_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej,
+                size_t nvars, const double *biases, const uint64_t *seeds, size_t R, int random_start, uint64_t t0,
+                const double *betas, const double *beta_replica, size_t timesteps,
+                uint8_t *states, double *energies_out, double *energies_per_step)
+{
+    gen_graph G;
+    gen_build(&G, n_edges, ea, eb, ej, nvars);
+    int k;
+    int32_t *jq_edge = malloc((n_edges ? n_edges : 1) * sizeof(int32_t)), *hq = malloc((nvars ? nvars : 1) * sizeof(int32_t));
+    orc_rj_quantise(n_edges, ea, eb, ej, nvars, biases, jq_edge, hq, &k);
+    /* quantised couplings in adjacency order (adj_build's fill order) */
+    int32_t *jq = malloc((G.A.ptr[nvars] ? G.A.ptr[nvars] : 1) * sizeof(int32_t));
+    {
+        size_t *fill = malloc((nvars + 1) * sizeof(size_t));
+        memcpy(fill, G.A.ptr, (nvars + 1) * sizeof(size_t));
+        for (size_t e = 0; e < n_edges; e++) {
+            if (ea[e] == eb[e]) continue;
+            jq[fill[ea[e]]++] = jq_edge[e];
+            jq[fill[eb[e]]++] = jq_edge[e];
+        }
+        free(fill);
+    }
+    double self_energy = 0.0;
+    for (size_t e = 0; e < n_edges; e++)
+        if (ea[e] == eb[e]) self_energy += ej[e];
+    size_t groups = (R + 31) / 32;
+    for (size_t g = 0; g < groups; g++) {
+        uint64_t key = seeds[32 * g];
+        uint8_t *S = states + 32 * g * nvars;
+        if (random_start)
+            for (size_t i = 0; i < nvars; i++) {
+                size_t p = G.pos[i];
+                uint32_t r[4];
+                size_t q = (p & 255) >> 6;
+                philox_seeded(key, 0, (uint32_t)(p - 64 * q), 0, DOM_PK_INIT, r);
+                for (int b = 0; b < 32; b++) S[(size_t)b * nvars + i] = (uint8_t)((r[q] >> b) & 1u);
+            }
+        for (size_t step = 0; step < timesteps; step++) {
+            uint64_t t = t0 + step;
+            uint32_t shift[32], mant[32]; /* the group's acceptance scales at this timestep */
+            for (int b = 0; b < 32; b++) {
+                size_t rr = 32 * g + b;
+                orc_rj_beta(beta_replica ? beta_replica[rr < R ? rr : R - 1] : betas[step], k, &shift[b], &mant[b]);
+            }
+            for (uint32_t c = 0; c < G.ncolours; c++)
+                for (size_t i = 0; i < nvars; i++) {
+                    if (G.colour[i] != c) continue;
+                    size_t p = G.pos[i];
+                    uint32_t words[8][4];
+                    for (uint32_t j = 0; j < 8; j++)
+                        philox_seeded(key, (uint32_t)t, (uint32_t)p, DOM_RJ_SWEEP, ctr2(t, 0, j), words[j]);
+                    for (int b = 0; b < 32; b++) {
+                        uint8_t *s = S + (size_t)b * nvars;
+                        int64_t field = 0;
+                        for (size_t e = G.A.ptr[i]; e < G.A.ptr[i + 1]; e++)
+                            field += (int64_t)jq[e] * (s[G.A.nbr[e]] ? 1 : -1);
+                        int64_t X = (s[i] ? 1 : -1) * ((int64_t)hq[i] - field);
+                        /* the sites of a colour class are independent: in place == simultaneous */
+                        if (orc_rj_accept((int32_t)X, words[b >> 2][b & 3], shift[b], mant[b])) s[i] = !s[i];
+                    }
+                }
+            if (energies_per_step)
+                for (int b = 0; b < 32 && 32 * g + b < R; b++)
+                    energies_per_step[(32 * g + b) * timesteps + step] =
+                        rj_energy(n_edges, ea, eb, jq_edge, nvars, hq, k, self_energy, S + (size_t)b * nvars);
+        }
+        if (energies_out)
+            for (int b = 0; b < 32 && 32 * g + b < R; b++)
+                energies_out[32 * g + b] = rj_energy(n_edges, ea, eb, jq_edge, nvars, hq, k, self_energy, S + (size_t)b * nvars);
+    }
+    free(jq_edge); free(hq); free(jq);
+    gen_free(&G);
+}

@@ -73,6 +73,18 @@ def lib():
                                   C.c_void_p, C.c_void_p]
         L.orc_pk_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, u64p, C.c_size_t, C.c_int, C.c_uint64,
                                  C.c_void_p, C.c_void_p, C.c_size_t, u8p, C.c_void_p, C.c_void_p]
+        L.orc_rj_log_table.argtypes = [u32p]
+        L.orc_rj_lambda.restype = C.c_uint32
+        L.orc_rj_lambda.argtypes = [C.c_uint32]
+        L.orc_rj_quantise.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_int)]
+        L.orc_rj_eligible.restype = C.c_int
+        L.orc_rj_eligible.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p]
+        L.orc_rj_beta.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_rj_accept.restype = C.c_int
+        L.orc_rj_accept.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_rj_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p, C.c_size_t, C.c_int,
+                                 C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, u8p, C.c_void_p, C.c_void_p]
         L.orc_pt_swap_round.restype = C.c_uint64
         L.orc_pt_swap_round.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, f64p, f64p, u32p]
         _LIB = L
@@ -232,5 +244,56 @@ def pk_run(ea, eb, ej, nvars, seeds, timesteps, betas=None, beta_replica=None, s
     e = np.zeros(R, dtype=np.float64)
     eps = np.zeros((R, timesteps), dtype=np.float64) if per_step else None
     lib().orc_pk_run(len(ea), ea, eb, ej, nvars, seeds, R, int(random_start), C.c_uint64(int(t0)), _ptr(b), _ptr(br),
+                     timesteps, st, _ptr(e), _ptr(eps))
+    return (e, st, eps) if per_step else (e, st)
+
+
+# ---- engine E: replica-packed real-coupling path ------------------------------------------
+def rj_log_table():
+    out = np.zeros(2049, dtype=np.uint32)
+    lib().orc_rj_log_table(out)
+    return out
+
+
+def rj_lambda(u):
+    return int(lib().orc_rj_lambda(C.c_uint32(int(u))))
+
+
+def rj_quantise(ea, eb, ej, nvars, biases=None):
+    """(k, jq per input edge, hq per site): couplings as integers in units of 2^k."""
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    jq, hq, k = np.zeros(len(ea), dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int()
+    lib().orc_rj_quantise(len(ea), ea, eb, ej, nvars, _ptr(b), _ptr(jq), _ptr(hq), C.byref(k))
+    return k.value, jq, hq
+
+
+def rj_eligible(ea, eb, ej, nvars, biases=None):
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    return bool(lib().orc_rj_eligible(len(ea), ea, eb, ej, nvars, _ptr(b)))
+
+
+def rj_beta(beta, k):
+    sh, mant = C.c_uint32(), C.c_uint32()
+    lib().orc_rj_beta(float(beta), int(k), C.byref(sh), C.byref(mant))
+    return sh.value, mant.value
+
+
+def rj_accept(X, u, shift, mant):
+    return bool(lib().orc_rj_accept(C.c_int32(int(X)), C.c_uint32(int(u)), C.c_uint32(shift), C.c_uint32(mant)))
+
+
+def rj_run(ea, eb, ej, nvars, seeds, timesteps, betas=None, beta_replica=None, biases=None, states=None, t0=0, per_step=False):
+    """Real-coupling spec engine (engine E); arguments and results as pk_run, plus site biases."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    R = len(seeds)
+    G = (R + 31) // 32
+    random_start = states is None
+    st = np.zeros((32 * G, nvars), dtype=np.uint8) if states is None else np.ascontiguousarray(states, dtype=np.uint8)
+    b = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+    br = None if beta_replica is None else np.ascontiguousarray(beta_replica, dtype=np.float64)
+    h = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    e = np.zeros(R, dtype=np.float64)
+    eps = np.zeros((R, timesteps), dtype=np.float64) if per_step else None
+    lib().orc_rj_run(len(ea), ea, eb, ej, nvars, _ptr(h), seeds, R, int(random_start), C.c_uint64(int(t0)), _ptr(b), _ptr(br),
                      timesteps, st, _ptr(e), _ptr(eps))
     return (e, st, eps) if per_step else (e, st)

@@ -18,7 +18,8 @@ class GraphInfo(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("jabs", C.c_double), ("uniform_sign", C.c_int32),
                 ("n_colours", C.c_uint32), ("state_words", C.c_uint64), ("fast_path", C.c_int32), ("open_x", C.c_int32),
                 ("open_y", C.c_int32), ("field", C.c_double), ("jabs_y", C.c_double),
-                ("field_signs", C.c_int32), ("packed_degree", C.c_int32)]
+                ("field_signs", C.c_int32), ("packed_degree", C.c_int32), ("real_slots", C.c_int32),
+                ("real_quantum_log2", C.c_int32)]
 
 
 _vp = C.c_void_p
@@ -34,6 +35,10 @@ _PROTOTYPES = {
     "isingmc_host_colour_graph": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint32)]),
     "isingmc_host_pt_swap_round": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp, _vp,
                                              C.POINTER(C.c_uint64)]),
+    "isingmc_host_rj_quantise": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int)]),
+    "isingmc_host_rj_beta": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "isingmc_host_rj_log_table": (C.c_int, [_vp]),
     "isingmc_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_uint, C.POINTER(_vp)]),
     "isingmc_graph_info": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
     "isingmc_graph_destroy": (None, [_vp]),
@@ -105,7 +110,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.isingmc_abi_version() != 2:
+        if L.isingmc_abi_version() != 3:
             raise RuntimeError("libisingmc.so ABI version mismatch")
         _lib = L
     return _lib
@@ -160,6 +165,26 @@ def recognise_lattice2d(ea, eb, ej, nvars):
         out.update(open_x=bool((ok.value - 1) & 2), open_y=bool((ok.value - 1) & 4))
     if ok.value > 0 and (ok.value - 1) & 8:  # jabs is the horizontal bonds' |J|, the vertical bonds have another
         out.update(anisotropic=True)
+    return out
+
+
+def rj_quantise(ea, eb, ej, nvars, biases=None):
+    """(k, jq per input edge, hq per site, eligible) of the real-coupling packed path."""
+    ea, eb, ej, b = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64), _arr(biases, np.float64)
+    jq, hq, k, ok = np.zeros(len(ea), dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int(), C.c_int()
+    _check(lib().isingmc_host_rj_quantise(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(b), _p(jq), _p(hq), C.byref(k), C.byref(ok)))
+    return k.value, jq, hq, bool(ok.value)
+
+
+def rj_beta(beta, k):
+    sh, mant = C.c_uint32(), C.c_uint32()
+    _check(lib().isingmc_host_rj_beta(float(beta), int(k), C.byref(sh), C.byref(mant)))
+    return sh.value, mant.value
+
+
+def rj_log_table():
+    out = np.zeros(2049, dtype=np.uint32)
+    _check(lib().isingmc_host_rj_log_table(_p(out)))
     return out
 
 

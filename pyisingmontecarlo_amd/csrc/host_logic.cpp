@@ -269,6 +269,64 @@ uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const doub
     return swaps;
 }
 
+// ---- replica-packed real-coupling path --------------------------------------------------------
+RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases)
+{
+    RjQuant Q;
+    double fmax = 0.0;
+    std::vector<double> mags; // nonzero |coupling| (every bond once) and |bias|
+    for (size_t i = 0; i < nvars; i++) {
+        double f = biases ? std::fabs(biases[i]) : 0.0;
+        if (f != 0.0) mags.push_back(f);
+        for (uint64_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) {
+            f += std::fabs(A.w[e]);
+            // every bond sits in the adjacency twice: taken from its lower-numbered end (duplicated bonds are separate terms)
+            if (A.nbr[e] > i && A.w[e] != 0.0) mags.push_back(std::fabs(A.w[e]));
+        }
+        fmax = std::max(fmax, f);
+        Q.max_degree = std::max<uint32_t>(Q.max_degree, uint32_t(A.ptr[i + 1] - A.ptr[i]));
+    }
+    Q.k = fmax > 0.0 ? std::ilogb(fmax) + 1 - 30 : 0;
+    Q.jq.resize(A.w.size());
+    for (size_t e = 0; e < A.w.size(); e++) Q.jq[e] = int32_t(std::nearbyint(std::ldexp(A.w[e], -Q.k)));
+    Q.hq.assign(nvars, 0);
+    if (biases)
+        for (size_t i = 0; i < nvars; i++) Q.hq[i] = int32_t(std::nearbyint(std::ldexp(biases[i], -Q.k)));
+    double median = 0.0; // the lower median
+    if (!mags.empty()) {
+        std::nth_element(mags.begin(), mags.begin() + (mags.size() - 1) / 2, mags.end());
+        median = mags[(mags.size() - 1) / 2];
+    }
+    Q.eligible = Q.max_degree <= 7 && fmax > 0.0 && fmax <= 64.0 * median;
+    return Q;
+}
+
+void rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
+{
+    uint32_t shift = 31, mant = 0xFFFFFFFFu; // beta <= 0: every attempt is accepted
+    if (beta > 0.0) {
+        const double kappa = std::ldexp(0.69314718055994530942 / (2.0 * beta), -k);
+        const int e = kappa > 0.0 && std::isfinite(kappa) ? std::ilogb(kappa) : (kappa > 0.0 ? 2000 : -2000);
+        const int r = std::max(e - 23, 0);
+        if (r <= 31) {
+            shift = uint32_t(r);
+            mant = uint32_t(std::floor(std::ldexp(kappa, 8 - r))); // kappa 2^-r < 2^24
+        }
+    }
+    *shift_out = shift;
+    *mant_out = mant;
+}
+
+void rj_log_table(uint32_t *out)
+{
+    const double h = 1.0 / 2048.0, LOG2E = 1.4426950408889634074;
+    out[0] = 0;
+    for (int i = 1; i <= 2048; i++) {
+        const double x = double(i) * h;
+        out[i] = uint32_t(std::nearbyint(std::ldexp(std::log2(1.0 + x) + h * h * LOG2E / (16.0 * (1.0 + x) * (1.0 + x)), 24) + 0.5));
+    }
+}
+
 } // namespace isingmc
 
 // ---- packed checkerboard planes -> one byte per spin (get_state copy-out, lattice.rs:209-211) ------------

@@ -64,6 +64,23 @@ Colouring greedy_colouring(const Adjacency &A, size_t nvars);
 uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
                        const double *slot_energy, uint32_t *perm);
 
+// ---- replica-packed real-coupling path: host halves of the spec ---------------------------
+// Couplings and biases as integers in units of 2^k: k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
+// jq in ADJACENCY order (A.w's), hq per site.  eligible: degree <= 7, Fmax > 0 and Fmax <= 64 x the median nonzero
+// |coupling or bias| (the absolute rounding error 2^(k-1) of a coupling then stays below 2^-25 of that median; one
+// enormous bias or coupling would otherwise set a quantum that wipes out the ordinary ones).
+struct RjQuant {
+    bool eligible = false;
+    int k = 0;
+    uint32_t max_degree = 0;
+    std::vector<int32_t> jq, hq;
+};
+RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases);
+// acceptance scale of beta: accept iff max(X >> shift, 0) <= (Lambda_q(u) * mant) >> 32
+void rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out);
+// LT[i], i = 0 .. 2048: log2(1 + i/2048) in Q24, centred for linear interpolation (see oracle/ising_oracle.c engine E)
+void rj_log_table(uint32_t *out);
+
 // packed checkerboard planes of one replica -> W*H bytes in site order (16 bytes per SSE2 store)
 void unpack_lattice(uint32_t W, uint32_t H, const uint32_t *words, uint8_t *spins);
 

@@ -22,6 +22,7 @@
 #include "lattice_kernels.hpp"
 #include "packed_kernels.hpp"
 #include "mc_types.hpp"
+#include "real_types.hpp"
 #include "strip_types.hpp"
 
 using namespace isingmc;
@@ -89,6 +90,11 @@ struct isingmc_graph {
     PkUniHeaders pk_uni{};
     std::vector<uint32_t> pk_class_full; // per colour class: end of its last 256-block without padding
     uint64_t n_directed = 0;
+    // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 7
+    bool rj_ok = false;
+    RjGraphDev rj{};
+    int rj_k = 0;                         // couplings are integers in units of 2^rj_k
+    std::vector<uint32_t> class_real_end; // per colour class: end of its real sites (the padding follows)
     std::vector<void *> dev_allocs;
 
     ~isingmc_graph()
@@ -127,6 +133,9 @@ struct isingmc_states {
     size_t pk_bit0 = 0; // replica r of this shard is bit (r + pk_bit0) % 32 of group (r + pk_bit0) / 32 (shards cut GLOBAL groups)
     size_t pk_slots() const { return 32 * groups; } // counter slots: one per (group, bit), owned or not
     uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
+    bool rj = false;           // packed container on the real-coupling path (real_kernels.hpp) instead of the bit-sliced one
+    RjBeta *d_rj_betas = nullptr; // per-replica acceptance scales [32 groups] (has_betas)
+    size_t n_total = 0, first = 0; // this container is the shard [first, first + R) of n_total experiments
     // persistent strip kernel (strip_kernels.hpp): halo granules, error word, tag epoch
     unsigned long long *d_halo = nullptr;
     size_t halo_cap = 0; // granules allocated
@@ -161,6 +170,7 @@ struct isingmc_states {
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)hipFree(p);
         if (d_tab) (void)hipFree(d_tab);
+        if (d_rj_betas) (void)hipFree(d_rj_betas);
         if (d_thr_mc) (void)hipFree(d_thr_mc);
         for (int b = 0; b < 2; b++) {
             for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
@@ -444,6 +454,45 @@ extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t 
     return ISINGMC_OK;
 }
 
+extern "C" int isingmc_host_rj_quantise(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars,
+                                        const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out, int *eligible_out)
+{
+    TRY(check_edges(ea, eb, ej, n_edges, nvars));
+    if (biases)
+        for (size_t i = 0; i < nvars; i++)
+            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
+    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
+    const RjQuant Q = rj_quantise(A, nvars, biases);
+    if (k_out) *k_out = Q.k;
+    if (eligible_out) *eligible_out = Q.eligible;
+    if (hq_out) std::copy(Q.hq.begin(), Q.hq.end(), hq_out);
+    if (jq_out) { // adjacency order -> input-edge order: edge e is the next unfilled entry of its first end's row
+        std::vector<uint64_t> fill(A.ptr.begin(), A.ptr.end());
+        for (size_t e = 0; e < n_edges; e++) {
+            if (ea[e] == eb[e]) { jq_out[e] = 0; continue; }
+            jq_out[e] = Q.jq[fill[ea[e]]];
+            fill[ea[e]]++;
+            fill[eb[e]]++;
+        }
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
+{
+    if (!shift_out || !mant_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (!std::isfinite(beta)) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
+    rj_beta(beta, k, shift_out, mant_out);
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_host_rj_log_table(uint32_t *table_out)
+{
+    if (!table_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    rj_log_table(table_out);
+    return ISINGMC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------
@@ -684,6 +733,51 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
             }
         }
     }
+    g->class_real_end.resize(C.n_colours);
+    for (uint32_t c = 0; c < C.n_colours; c++) { // real sites come first in a class
+        uint32_t real = 0;
+        while (uint32_t(C.class_base[c]) + real < uint32_t(C.class_base[c + 1]) && site[uint32_t(C.class_base[c]) + real] != PAD_SITE) real++;
+        g->class_real_end[c] = uint32_t(C.class_base[c]) + real;
+    }
+    // real-coupling packed path: whatever the bit-sliced packed path cannot take (couplings of several sizes, site
+    // biases), degree <= 7, quantisation faithful (rj_quantise)
+    if (!g->packed_ok && n_pos < 0x80000000u) {
+        const RjQuant Q = rj_quantise(A, nvars, biases);
+        if (Q.eligible) {
+            const uint32_t slots = Q.max_degree <= 4 ? 4u : 7u;
+            std::vector<uint32_t> enbr(size_t(slots) * n_pos);
+            std::vector<int32_t> ejq(size_t(slots) * n_pos, 0), ehq(n_pos, 0);
+            for (uint32_t i = 0; i < slots; i++)
+                for (uint32_t p = 0; p < n_pos; p++) enbr[size_t(i) * n_pos + p] = p; // unused slots point at the own position
+            for (uint32_t p = 0; p < n_pos; p++) {
+                if (site[p] == PAD_SITE) continue;
+                ehq[p] = Q.hq[site[p]];
+                uint32_t i = 0;
+                for (uint64_t e = A.ptr[site[p]]; e < A.ptr[site[p] + 1]; e++, i++) {
+                    enbr[size_t(i) * n_pos + p] = uint32_t(C.pos[A.nbr[e]]);
+                    ejq[size_t(i) * n_pos + p] = Q.jq[e];
+                }
+            }
+            uint32_t lt[RJ_LOG_INTERVALS + 1];
+            rj_log_table(lt);
+            std::vector<uint2> logtab(RJ_LOG_INTERVALS);
+            for (int i = 0; i < RJ_LOG_INTERVALS; i++) logtab[i] = make_uint2(lt[i], lt[i + 1] - lt[i]);
+            RjGraphDev &J = g->rj;
+            TRY(graph_upload(g, &J.nbr, enbr));
+            TRY(graph_upload(g, &J.jq, ejq));
+            TRY(graph_upload(g, &J.hq, ehq));
+            TRY(graph_upload(g, &J.logtab, logtab));
+            J.n_pos = n_pos;
+            J.slots = slots;
+            g->rj_k = Q.k;
+            g->rj_ok = true;
+            // the packed containers' common parts (random start, set_state, copy-out) read these
+            g->pk.site = D.site;
+            g->pk.class_base = D.class_base;
+            g->pk.n_colours = D.n_colours;
+            g->pk.n_pos = n_pos;
+        }
+    }
     D.bias = nullptr;
     if (g->has_bias) {
         std::vector<double> bias(n_pos, 0.0);
@@ -744,6 +838,8 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
     }
     info->n_colours = g->n_colours;
     info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
+    info->real_slots = g->rj_ok ? int32_t(g->rj.slots) : 0;
+    info->real_quantum_log2 = g->rj_ok ? g->rj_k : 0;
     info->state_words = g->state_words;
     return ISINGMC_OK;
 }
@@ -764,7 +860,7 @@ constexpr size_t MAX_GRID_Y = 32768;
 static int lanes_reserve(isingmc_states *s, size_t n);
 
 // replica-packed general path (defined further down)
-static bool choose_packed(const isingmc_graph *g, size_t n_replicas);
+static int choose_packed(const isingmc_graph *g, size_t n_replicas);
 static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state);
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
 static int pk_set_betas(isingmc_states *s);
@@ -875,7 +971,10 @@ extern "C" int isingmc_states_create_range(isingmc_graph *g, size_t n_total, con
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     TRY(lanes_reserve(s.get(), 2)); // created up front: the first multi-lane run must not pay for stream creation
-    if (choose_packed(g, n_total) && count) {
+    s->n_total = n_total;
+    s->first = first;
+    if (const int mode = count ? choose_packed(g, n_total) : 0) {
+        s->rj = mode == 2;
         TRY(pk_create(s.get(), all_seeds, first, count, initial_state));
     } else {
         TRY(reserve(s.get(), std::max<size_t>(count, 1)));
@@ -934,10 +1033,10 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
     for (size_t r = 0; r < s->R; r++)
         if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
-    if (s->packed && s->pk_bit0 != 0 && !all_equal)
+    if (s->packed && !s->rj && !all_equal && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
         // the replicas of a group number their ties together: a group's trajectory depends on all 32 betas, and this
-        // shard only knows its own
-        return fail(ISINGMC_ERR_INVALID, "per-replica betas on a replica-packed shard: the shard must start on a multiple of 32 experiments");
+        // shard only knows its own (the real-coupling path decides every replica on its own: any cut is fine there)
+        return fail(ISINGMC_ERR_INVALID, "per-replica betas on a replica-packed shard: the shard must start and end on multiples of 32 experiments (or at the last experiment)");
     s->betas.assign(beta_per_replica, beta_per_replica + s->R);
     if (s->packed) {
         if (s->R) TRY(pk_set_betas(s));
@@ -973,6 +1072,12 @@ static bool env_flag(const char *name)
     return e && e[0] && e[0] != '0';
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *e = std::getenv(name);
+    return e && e[0] ? std::atoi(e) : dflt;
+}
+
 // worth it from 16 replicas on and when the graph is too big for the LDS-resident per-replica kernel
 // LDS-resident kernel for small graphs only: one workgroup walks a whole replica, ~13 us + 2.8..5 ns per site
 // and timestep whatever the replica count, against ~5 us per colour class for the per-colour launches --
@@ -983,13 +1088,18 @@ static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
     return g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && g->nvars <= (n_replicas < 16 ? 8000u : 12000u);
 }
 
-static bool choose_packed(const isingmc_graph *g, size_t n_replicas)
+// 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
+static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
-    if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return false;
+    if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL")) {
+        if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
+        return n_replicas >= 16 && !gen_resident_fits(g, n_replicas) ? 2 : 0;
+    }
+    if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
-    if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return false;
-    if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0;
-    return n_replicas >= 16 && !gen_resident_fits(g, n_replicas);
+    if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
+    if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0 ? 1 : 0;
+    return n_replicas >= 16 && !gen_resident_fits(g, n_replicas) ? 1 : 0;
 }
 
 // threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)
@@ -1062,6 +1172,17 @@ static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins)
 
 static int pk_set_betas(isingmc_states *s)
 {
+    if (s->rj) { // one acceptance scale per (group, bit); bits this shard does not own take the nearest owned replica's
+        std::vector<RjBeta> tab(32 * s->groups);
+        for (size_t sl = 0; sl < tab.size(); sl++) {
+            const size_t r = sl < s->pk_bit0 ? 0 : std::min(s->R - 1, sl - s->pk_bit0);
+            rj_beta(s->betas[r], s->g->rj_k, &tab[sl].shift, &tab[sl].mant);
+        }
+        if (!s->d_rj_betas) TRY(dev_alloc(&s->d_rj_betas, tab.size()));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(s->d_rj_betas, tab.data(), tab.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
+        return ISINGMC_OK;
+    }
     std::vector<uint32_t> tabs(s->groups * PK_TAB_WORDS);
     for (size_t k = 0; k < s->groups; k++)
         pk_fill_table(tabs.data() + k * PK_TAB_WORDS, s->g->jabs,
@@ -1070,6 +1191,25 @@ static int pk_set_betas(isingmc_states *s)
     HIP_TRY(hipStreamSynchronize(s->stream)); // no launch may still be reading the old tables
     HIP_TRY(hipMemcpy(s->d_tab, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return ISINGMC_OK;
+}
+
+// real-coupling path: one launch per colour class; a workgroup walks several 256-position blocks (it loads the log table once)
+static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t beta_stride)
+{
+    const isingmc_graph *g = s->g;
+    static const int target_wgs = std::max(256, env_int("ISINGMC_REAL_TARGET_WGS", 3072));
+    for (uint32_t c = 0; c < g->n_colours; c++) {
+        const uint32_t b = uint32_t(g->class_base[c]), e = g->class_real_end[c];
+        if (e == b) continue;
+        const size_t nblocks = (size_t(e - b) + 255) / 256;
+        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+            const size_t gx0 = std::min(nblocks, std::max<size_t>(1, (size_t(target_wgs) + ng - 1) / ng));
+            const size_t per = (nblocks + gx0 - 1) / gx0, gx = (nblocks + per - 1) / per; // equal shares, no short last round
+            (void)rj_launch_sweep(dim3(unsigned(gx), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj, b, e, s->t,
+                                  s->d_keys + g0, betas + (beta_stride ? g0 * beta_stride : 0), beta_stride);
+        }
+    }
 }
 
 static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride)
@@ -1098,6 +1238,15 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
 
 static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot);
 
+// energy of one replica of a packed container from the first counter of its slot
+static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0)
+{
+    // real-coupling path: c0 = sum_i (X_i + s_i hq_i) = -2 x the energy in units of 2^k (an exact integer)
+    if (rj) return std::ldexp(double(-(int64_t(c0) / 2)), g->rj_k) + g->self_energy;
+    // bit-sliced path: E = |J| (undirected bonds - 2 satisfied) + self loops; c0 = directed satisfied count (doubled)
+    return g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(c0))) + g->self_energy;
+}
+
 static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
 {
     const isingmc_graph *g = s->g;
@@ -1107,9 +1256,9 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     std::vector<unsigned long long> h(2 * s->pk_slots());
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    for (size_t r = 0; r < R; r++) { // E = |J| (undirected bonds - 2 satisfied) + self loops; directed counts are doubled
+    for (size_t r = 0; r < R; r++) {
         const size_t sl = r + s->pk_bit0;
-        if (energies) energies[r] = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h[2 * sl]))) + g->self_energy;
+        if (energies) energies[r] = pk_energy(g, s->rj, h[2 * sl]);
         if (mags) mags[r] = 2 * int64_t(h[2 * sl + 1]) - int64_t(g->nvars);
     }
     return ISINGMC_OK;
@@ -1122,8 +1271,11 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     const size_t R = s->R, CS = s->pk_slots();
     DeviceScratch scratch(s->stream);
     uint32_t *d_step_tabs = nullptr;
+    RjBeta *d_rj_steps = nullptr; // real-coupling path: one acceptance scale per timestep of the chunk
+    std::vector<RjBeta> h_rj;
     const size_t chunk = std::min<size_t>(timesteps, 2048);
-    if (!s->has_betas) TRY(scratch.alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
+    if (!s->has_betas && s->rj) TRY(scratch.alloc(&d_rj_steps, beta_stride ? chunk : 1));
+    else if (!s->has_betas) TRY(scratch.alloc(&d_step_tabs, (beta_stride ? chunk : 1) * PK_TAB_WORDS));
     // energies after every timestep: the measurements are enqueued behind their sweeps into one counter slot
     // per step; the host reads a whole chunk at once
     unsigned long long *d_step_counts = nullptr;
@@ -1137,7 +1289,11 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
-        if (!s->has_betas && (beta_stride || k0 == 0)) {
+        if (!s->has_betas && s->rj && (beta_stride || k0 == 0)) {
+            h_rj.resize(beta_stride ? nk : 1);
+            for (size_t k = 0; k < h_rj.size(); k++) rj_beta(betas[(k0 + k) * beta_stride], g->rj_k, &h_rj[k].shift, &h_rj[k].mant);
+            HIP_TRY(hipMemcpy(d_rj_steps, h_rj.data(), h_rj.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
+        } else if (!s->has_betas && (beta_stride || k0 == 0)) {
             h_tabs.resize((beta_stride ? nk : 1) * PK_TAB_WORDS);
             for (size_t k = 0; k < h_tabs.size() / PK_TAB_WORDS; k++) {
                 const double beta = betas[(k0 + k) * beta_stride];
@@ -1146,7 +1302,10 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             HIP_TRY(hipMemcpy(d_step_tabs, h_tabs.data(), h_tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
         for (size_t k = 0; k < nk && rc == ISINGMC_OK; k++) {
-            if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
+            if (s->rj) {
+                if (s->has_betas) rj_launch_timestep(s, s->d_rj_betas, 32);
+                else rj_launch_timestep(s, d_rj_steps + (beta_stride ? k : 0), 0);
+            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
             else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
             s->t++;
             if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * CS * 2, nullptr, nullptr);
@@ -1155,9 +1314,8 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             HIP_TRY(hipMemcpyAsync(h_step_counts.data(), d_step_counts, nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
             for (size_t k = 0; k < nk; k++)
-                for (size_t r = 0; r < R; r++) // as in pk_measure: directed counts are doubled
-                    energies_per_step[r * timesteps + k0 + k] =
-                        g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_step_counts[(k * CS + r + s->pk_bit0) * 2]))) + g->self_energy;
+                for (size_t r = 0; r < R; r++)
+                    energies_per_step[r * timesteps + k0 + k] = pk_energy(g, s->rj, h_step_counts[(k * CS + r + s->pk_bit0) * 2]);
         } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (device_ms && rc == ISINGMC_OK) {
@@ -1430,12 +1588,6 @@ struct StripPlan {
     StripArgs a{};
     size_t replicas_per_pass = 0; // a pass = one launch over a block of replicas for all timesteps of the chunk
 };
-
-static int env_int(const char *name, int dflt)
-{
-    const char *e = std::getenv(name);
-    return e && e[0] ? std::atoi(e) : dflt;
-}
 
 // Mid-size lattices only: a per-colour launch of the streaming kernel must be short enough for the ~5 us it loses
 // between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups in all, default the resident limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
@@ -1861,6 +2013,16 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
     const size_t R = s->R;
     if (s->packed) { // counts_slot: [pk_slots()][2], one pair per (group, bit) -- a shard may own only some bits of a group
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * s->pk_slots() * sizeof(unsigned long long), s->stream));
+        if (s->rj) {
+            const size_t nblocks = g->pk.n_pos / 256;
+            for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
+                const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+                const size_t gx = std::min(nblocks, std::max<size_t>(1, (1536 + ng - 1) / ng));
+                HIP_TRY(rj_launch_measure(dim3(unsigned(gx), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj, g->pk.site,
+                                          counts_slot + 2 * 32 * g0));
+            }
+            return ISINGMC_OK;
+        }
         uint32_t ppt = PK_MEASURE_POS_PER_THREAD; // halved until the launch has >= 1024 workgroups (not below 8: the transpose
                                                   // at the end of a chunk costs as much as ~16 positions)
         while (ppt > 8 && size_t((g->pk.n_pos + 256 * ppt - 1) / (256 * ppt)) * s->groups < 1024) ppt /= 2;
@@ -1999,7 +2161,7 @@ extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t therm
                 const uint32_t *w = h_samples + k * words + (sl / 32) * g->pk.n_pos;
                 const uint32_t bit = uint32_t(sl % 32);
                 for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
-                energy = g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(h_counts[(k * CS + sl) * 2]))) + g->self_energy;
+                energy = pk_energy(g, s->rj, h_counts[(k * CS + sl) * 2]);
             } else {
                 unpack_state(g, h_samples + k * words + r * g->state_words, out);
                 if (counts) energy = lattice_energy(g, h_counts[(k * R + r) * 2], h_counts[(k * R + r) * 2 + 1]);

@@ -1,0 +1,214 @@
+// Replica-packed path for REAL couplings and arbitrary site biases: what the reference's f64 edge list
+// (lattice.rs:46-50) and set_individual_bias / set_global_bias (lattice.rs:104-131, materialised at :186-189) can express and
+// the bit-sliced kernels cannot -- Gaussian spin glasses, random fields, one biased site on an otherwise uniform lattice.
+//
+// Layout as the packed path (packed_kernels.hpp): colour-major positions, one 32-bit word per POSITION holding the spins
+// of a group of 32 replicas.  One thread owns one position and decides its 32 replicas:
+//   1. gather the own word and the <= 7 neighbour words; a_e = own ^ neighbour_e (bit b: replica b's bond e is antiparallel);
+//   2. the half energy change of a flip, X = s (hq - sum_e Jq_e s_e) = (s hq) - sum_e Jq_e + 2 sum_{e: a_e} Jq_e, depends on
+//      the replica only through the index (a_0 .. a_{d-1}, own): its <= 32 values go into a per-thread column of LDS
+//      (layout [entry][thread]: conflict-free), built with 15 + 32 integer adds per 32 replicas;
+//   3. an 8 x 32 bit-matrix transposition (12 delta swaps of 4 instructions) turns the 8 words into 32 index bytes;
+//   4. per replica: one 32-bit Philox word u (8 Philox4x32-10 calls per position = 4 attempts per call), Lambda_q(u) ~
+//      -log2(u 2^-32) in Q24 from the bits of float(u) and a 2048-entry LDS table with linear interpolation, and the
+//      integer test  max(X >> shift, 0) <= (Lambda_q * mant) >> 32  -- no exp, no f64, no 53-bit uniform per attempt.
+// The CPU oracle (engine E, oracle/ising_oracle.c) takes the same decisions spin by spin from a direct integer field sum.
+#pragma once
+#include "philox.hpp"
+#include "real_types.hpp"
+
+namespace isingmc {
+
+constexpr int RJ_THREADS = 256;
+constexpr uint32_t RJ_PAD_SITE = 0xFFFFFFFFu; // == PAD_SITE (general_kernels.hpp)
+
+// One step of the transposition: swap the high sub-blocks (bits m << s) of x with the low sub-blocks (bits m) of y.
+__device__ __forceinline__ void rj_delta_swap(uint32_t &x, uint32_t &y, const uint32_t m, const int s)
+{
+    const uint32_t x2 = (m & x) | (~m & (y << s)); // v_lshlrev + v_bfi
+    const uint32_t y2 = (m & (x >> s)) | (~m & y); // v_lshrrev + v_bfi
+    x = x2;
+    y = y2;
+}
+
+// w[c] bit b (c = index bit, b = replica)  ->  w[b & 7] byte (b >> 3) = the index of replica b (bit c = old w[c] bit b)
+__device__ __forceinline__ void rj_transpose(uint32_t (&w)[8])
+{
+    rj_delta_swap(w[0], w[1], 0x55555555u, 1); rj_delta_swap(w[2], w[3], 0x55555555u, 1);
+    rj_delta_swap(w[4], w[5], 0x55555555u, 1); rj_delta_swap(w[6], w[7], 0x55555555u, 1);
+    rj_delta_swap(w[0], w[2], 0x33333333u, 2); rj_delta_swap(w[1], w[3], 0x33333333u, 2);
+    rj_delta_swap(w[4], w[6], 0x33333333u, 2); rj_delta_swap(w[5], w[7], 0x33333333u, 2);
+    rj_delta_swap(w[0], w[4], 0x0F0F0F0Fu, 4); rj_delta_swap(w[1], w[5], 0x0F0F0F0Fu, 4);
+    rj_delta_swap(w[2], w[6], 0x0F0F0F0Fu, 4); rj_delta_swap(w[3], w[7], 0x0F0F0F0Fu, 4);
+}
+
+// Lambda_q(u): Q24 fixed point of 32 - log2(u) from the exponent field and the top mantissa bits of float(u) (round to
+// nearest even), s_log[i] = {LT[i], LT[i+1] - LT[i]}; 159 << 24 for u = 0, 0 when u rounds up to 2^32
+__device__ __forceinline__ uint32_t rj_lambda(const uint32_t u, const uint2 *s_log)
+{
+    const uint32_t bits = __float_as_uint(__uint2float_rn(u));
+    const uint2 e = s_log[(bits >> 12) & 0x7FFu];
+    const uint32_t val = e.x + __umulhi(e.y, bits << 20); // LT + ((D * low 12 mantissa bits) >> 12)
+    return (159u << 24) - ((bits >> 23) << 24) - val;
+}
+
+// The per-thread column of X values.  SLOTS == 4: one table of 32 entries indexed by (a_0..a_3, own);
+// SLOTS == 7: two tables of 16, A indexed by (a_0..a_3) and B by (a_4, a_5, a_6, own), X = A + B.
+// HSCALE: 1 for the sweep (X), 2 for the measurement (X + s hq = 2 s hq - SJ + 2 sum_{a} Jq).
+// FOLD: store max(X >> shift, 0) (one beta for all replicas, SLOTS == 4) instead of X.
+template <int SLOTS, int HSCALE, bool FOLD>
+__device__ __forceinline__ void rj_build_tables(uint32_t *s_x, const uint32_t tid, const int32_t (&jq)[SLOTS], const int32_t hq,
+                                                const uint32_t shift)
+{
+    int32_t sj = 0;
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) sj += jq[e];
+    int32_t sub[16]; // 2 x subset sums of the first four couplings
+    sub[0] = 0;
+#pragma unroll
+    for (int n = 1; n < 16; n++) sub[n] = sub[n & (n - 1)] + 2 * jq[__builtin_ctz(n) < SLOTS ? __builtin_ctz(n) : 0];
+    if constexpr (SLOTS == 4) {
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int32_t x0 = sub[n] - sj - HSCALE * hq, x1 = sub[n] - sj + HSCALE * hq; // own spin down / up
+            if constexpr (FOLD) {
+                s_x[n * RJ_THREADS + tid] = uint32_t(max(x0 >> shift, 0));
+                s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(max(x1 >> shift, 0));
+            } else {
+                s_x[n * RJ_THREADS + tid] = uint32_t(x0);
+                s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(x1);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < 16; n++) s_x[n * RJ_THREADS + tid] = uint32_t(sub[n]);
+        int32_t subb[8];
+        subb[0] = 0;
+#pragma unroll
+        for (int n = 1; n < 8; n++) subb[n] = subb[n & (n - 1)] + 2 * jq[4 + __builtin_ctz(n)];
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(subb[n] - sj - HSCALE * hq);
+            s_x[(24 + n) * RJ_THREADS + tid] = uint32_t(subb[n] - sj + HSCALE * hq);
+        }
+    }
+}
+
+// X (or the folded threshold operand) of the replica whose index byte is `idx`
+template <int SLOTS>
+__device__ __forceinline__ uint32_t rj_lookup(const uint32_t *s_x, const uint32_t tid, const uint32_t idx)
+{
+    if constexpr (SLOTS == 4) return s_x[idx * RJ_THREADS + tid];
+    else return s_x[(idx & 15u) * RJ_THREADS + tid] + s_x[(16u + (idx >> 4)) * RJ_THREADS + tid];
+}
+
+// gather: own word, neighbour words, couplings, bias of position p; w[] = the 8 index words before transposition
+template <int SLOTS>
+__device__ __forceinline__ void rj_gather(const uint32_t *__restrict__ st, const RjGraphDev &G, const uint32_t p, uint32_t &own,
+                                          int32_t (&jq)[SLOTS], int32_t &hq, uint32_t (&w)[8])
+{
+    uint32_t q[SLOTS];
+    own = st[p];
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) q[e] = G.nbr[size_t(e) * G.n_pos + p];
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) jq[e] = G.jq[size_t(e) * G.n_pos + p];
+    hq = G.hq[p];
+#pragma unroll
+    for (int e = 0; e < 8; e++) w[e] = 0u;
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) w[e] = own ^ st[q[e]];
+    w[SLOTS == 4 ? 4 : 7] = own;
+}
+
+// one colour class of one timestep; blockIdx.y = replica group; a workgroup walks 256-position blocks of the class
+template <int SLOTS, bool UB>
+__global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
+                                                              const uint32_t real_end, const uint64_t t,
+                                                              const uint2 *__restrict__ group_keys, const RjBeta *__restrict__ betas)
+{
+    __shared__ uint2 s_log[RJ_LOG_INTERVALS];
+    __shared__ uint32_t s_x[32 * RJ_THREADS];
+    const uint32_t tid = threadIdx.x, g = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < RJ_LOG_INTERVALS / RJ_THREADS; i++) s_log[tid + RJ_THREADS * i] = G.logtab[tid + RJ_THREADS * i];
+    __syncthreads();
+    uint32_t *st = state + size_t(g) * G.n_pos;
+    const uint2 key = group_keys[g];
+    const PhiloxVKeys vk = philox_vkeys(key);
+    const RjBeta *gb = betas + (UB ? 0 : size_t(32) * g);
+    constexpr bool FOLD = UB && SLOTS == 4;
+    const uint32_t shift0 = gb[0].shift, mant0 = gb[0].mant;
+
+    for (uint32_t base = class_begin + blockIdx.x * RJ_THREADS; base < real_end; base += gridDim.x * RJ_THREADS) {
+        const uint32_t p = base + tid;
+        if (p >= real_end) continue; // (no barrier below: a thread reads only its own column of s_x)
+        uint32_t own, w[8];
+        int32_t jq[SLOTS], hq;
+        rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
+        rj_build_tables<SLOTS, 1, FOLD>(s_x, tid, jq, hq, shift0);
+        rj_transpose(w);
+        uint32_t flips = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { // Philox call j serves replica bits 4j .. 4j+3
+            const uint4 rnd = philox4x32_10(make_uint4(uint32_t(t), p, DOM_RJ_SWEEP, ctr2(t, 0, uint32_t(j))), key, vk);
+            const uint32_t u4[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = 4 * j + i;
+                const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
+                const uint32_t xv = rj_lookup<SLOTS>(s_x, tid, idx);
+                const uint32_t shift = UB ? shift0 : gb[b].shift, mant = UB ? mant0 : gb[b].mant;
+                const uint32_t xpos = FOLD ? xv : uint32_t(max(int32_t(xv) >> shift, 0));
+                const uint32_t y = __umulhi(rj_lambda(u4[i], s_log), mant);
+                flips |= uint32_t(xpos <= y) << b;
+            }
+        }
+        st[p] = own ^ flips;
+    }
+}
+
+// sum over the real positions of (X + s hq) and of the up spins, per replica.  A thread walks positions
+// blockIdx.x * 256 + tid, + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
+template <int SLOTS>
+__global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *__restrict__ state, const RjGraphDev G,
+                                                                const uint32_t *__restrict__ site, unsigned long long *__restrict__ out)
+{
+    __shared__ uint32_t s_x[32 * RJ_THREADS];
+    const uint32_t tid = threadIdx.x, g = blockIdx.y;
+    const uint32_t *st = state + size_t(g) * G.n_pos;
+    long long acc[32];
+    uint32_t up[32];
+#pragma unroll
+    for (int b = 0; b < 32; b++) { acc[b] = 0; up[b] = 0; }
+    for (uint32_t p = blockIdx.x * RJ_THREADS + tid; p < G.n_pos; p += gridDim.x * RJ_THREADS) {
+        if (site[p] == RJ_PAD_SITE) continue;
+        uint32_t own, w[8];
+        int32_t jq[SLOTS], hq;
+        rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
+        rj_build_tables<SLOTS, 2, false>(s_x, tid, jq, hq, 0u);
+        rj_transpose(w);
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
+            acc[b] += (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, idx));
+            up[b] += (own >> b) & 1u;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        long long a = acc[b];
+        uint32_t u = up[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a += __shfl_xor(a, off);
+            u += __shfl_xor(u, off);
+        }
+        if ((tid & 63u) == 0 && (a != 0 || u != 0)) {
+            atomicAdd(out + 2 * (size_t(32) * g + b), (unsigned long long)a);
+            atomicAdd(out + 2 * (size_t(32) * g + b) + 1, (unsigned long long)u);
+        }
+    }
+}
+
+} // namespace isingmc

@@ -1,0 +1,44 @@
+// Shared declarations of the replica-packed REAL-COUPLING path (real_kernels.hpp): any f64 couplings and
+// any site biases -- the edge list of lattice.rs:46-50 with set_individual_bias / set_global_bias (lattice.rs:104-131)
+// materialised as lattice.rs:186-189 does -- on graphs of degree <= 7.  Own translation unit (real_kernels.hip), like the
+// strip and multi-class kernels, so that the streaming lattice kernels keep their register allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace isingmc {
+
+constexpr int RJ_MAX_DEG = 7;
+constexpr uint32_t DOM_RJ_SWEEP = 0x524A5357u; // "RJSW"
+constexpr int RJ_LOG_INTERVALS = 2048;         // intervals of the log2(1 + m) table (Q24 values, linear interpolation)
+
+// ELL view of the quantised graph, slot-major (a wave's 64 positions read 256 contiguous bytes per slot).
+// Couplings and biases are integers in units of 2^k (k chosen once per graph, host_logic.cpp rj_quantise).
+struct RjGraphDev {
+    const uint32_t *nbr; // [slots][n_pos] neighbour position; the own position in the unused slots of a site
+    const int32_t *jq;   // [slots][n_pos] quantised coupling; 0 in unused slots
+    const int32_t *hq;   // [n_pos] quantised bias (0 on padding)
+    const uint2 *logtab; // [RJ_LOG_INTERVALS] {LT[i], LT[i+1] - LT[i]}
+    uint32_t n_pos;      // multiple of 256
+    uint32_t slots;      // 4 (every site has degree <= 4) or 7
+};
+
+// acceptance scale of one inverse temperature: accept iff max(X >> shift, 0) <= (Lambda_q(u) * mant) >> 32
+struct RjBeta {
+    uint32_t shift, mant;
+};
+
+// One colour class of one timestep.  Positions [class_begin, real_end) are the real sites of the class (the padding behind
+// them is left alone); grid.y = replica groups.  betas: beta_stride == 0: one RjBeta for every replica of the launch;
+// beta_stride == 32: betas[32 g + b] for replica bit b of group g.
+hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
+                           uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride);
+
+// out[2 slot] += sum over the real positions in [0, n_pos) of (X + s hq) (an int64 in two's complement: the energy in units
+// of 2^k is minus half of it), out[2 slot + 1] += up spins; slot = 32 g + b.  class_real_end: device array of the ends of the
+// real sites per colour class is not needed here: padding carries the PAD marker in `site`.
+hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
+                             unsigned long long *out);
+
+} // namespace isingmc

@@ -9,6 +9,9 @@ ships no tests, fixtures or golden vectors and cannot be built here (SURVEY.md s
   make_seeds.json      oracle make_seeds (SplitMix64 -> xoshiro256++), regression pin for oracle == library
   kaufman.json         exact finite-torus energies from oracle/exact.py (Kaufman 1949)
   lattice_sweeps.json  sha256 of oracle checkerboard configurations: regression pin of the spec
+  real_path.json       real-coupling packed path: sha256 of the log2 table (it comes out of libm's log2: the pin
+                       detects a libm that rounds an entry the other way) and Lambda_q(u) known answers; a sha256 of engine E
+                       configurations on a small Gaussian glass: regression pin of the spec
 """
 import hashlib
 import json
@@ -64,6 +67,18 @@ def main():
         sweeps.append({"W": W, "H": H, "jabs": jabs, "jpos": jpos, "j_seed": j_seed, "beta": beta, "seed": seed,
                        "T": T, "sha256": hashlib.sha256(st.tobytes()).hexdigest(), "energy": lat.energy_mag(st)[0]})
     dump("lattice_sweeps.json", {"source": "oracle engine B (checkerboard spec), N_PLANES = 7", "cases": sweeps})
+    lt = O.rj_log_table()
+    rng = np.random.default_rng(99)
+    us = [0, 1, 2, 3, 255, 256, 65535, 65536, 2 ** 24 - 1, 2 ** 24, 2 ** 24 + 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 129,
+          2 ** 32 - 128] + [int(x) for x in rng.integers(0, 2 ** 32, 40, dtype=np.uint64)]
+    ea, eb, _ = X.square_lattice_edges(12, 10, 1.0)
+    grng = np.random.default_rng(7)
+    ej, h = grng.normal(size=len(ea)), grng.normal(size=120) * 0.3
+    e, st = O.rj_run(ea, eb, ej, 120, O.make_seeds(5, 40), 6, betas=[0.8] * 6, biases=h)
+    dump("real_path.json", {"source": "oracle engine E (real-coupling packed spec)",
+                            "log_table_sha256": hashlib.sha256(lt.tobytes()).hexdigest(),
+                            "lambda": [[u, O.rj_lambda(u)] for u in us],
+                            "glass_12x10": {"sha256": hashlib.sha256(st[:40].tobytes()).hexdigest(), "energy0": float(e[0])}})
 
 
 if __name__ == "__main__":

@@ -1,0 +1,171 @@
+"""GPU parity of the replica-packed REAL-COUPLING path (csrc/real_kernels.hpp) against oracle engine E,
+bit for bit: Gaussian couplings on a 2-d lattice, a random real-J graph with biases (degree up to 7), one biased site on
+an otherwise uniform lattice (Lattice.set_individual_bias, lattice.rs:104-127), per-replica betas, per-step energies
+(lattice.rs:445-455), sampling, shards that cut a replica group, and the Boltzmann averages of a 16-spin graph (K2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_graph(rng, n, m, maxdeg, skip=0):
+    pairs, deg = set(), np.zeros(n, dtype=int)
+    while len(pairs) < m:
+        a, b = (int(v) for v in rng.integers(0, n - skip, 2))
+        if a != b and deg[a] < maxdeg and deg[b] < maxdeg and (min(a, b), max(a, b)) not in pairs:
+            pairs.add((min(a, b), max(a, b)))
+            deg[a] += 1
+            deg[b] += 1
+    pairs = sorted(pairs)
+    rng.shuffle(pairs)
+    return np.array([p[0] for p in pairs], dtype=np.uint64), np.array([p[1] for p in pairs], dtype=np.uint64)
+
+
+def _case(capi, oracle, ea, eb, ej, nvars, R, T, beta=None, beta_replica=None, biases=None, initial=None, slots=None):
+    seeds = capi.make_seeds(77, R)
+    g = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
+    assert g.kind == capi.KIND_GENERAL and g.info.real_slots == (slots or g.info.real_slots) and g.info.real_slots in (4, 7)
+    assert g.info.real_quantum_log2 == oracle.rj_quantise(ea, eb, ej, nvars, biases)[0]
+    st = capi.States(g, seeds, initial_state=initial)
+    ref_states = None if initial is None else np.tile(np.asarray(initial, dtype=np.uint8), (32 * ((R + 31) // 32), 1))
+    if beta_replica is not None:
+        st.set_betas(beta_replica)
+        eps = st.do_time_steps(T, per_step_energies=True)
+        e_ref, s_ref, eps_ref = oracle.rj_run(ea, eb, ej, nvars, seeds, T, beta_replica=beta_replica, biases=biases,
+                                              states=ref_states, per_step=True)
+    else:
+        betas = [beta] * T if np.ndim(beta) == 0 else beta
+        eps = st.do_time_steps(T, beta, per_step_energies=True)
+        e_ref, s_ref, eps_ref = oracle.rj_run(ea, eb, ej, nvars, seeds, T, betas=betas, biases=biases, states=ref_states,
+                                              per_step=True)
+    np.testing.assert_array_equal(st.states().astype(np.uint8), s_ref[:R])
+    np.testing.assert_array_equal(eps, eps_ref)            # exact integer sums scaled by a power of two: bit-equal
+    np.testing.assert_array_equal(st.energies(), e_ref)
+    np.testing.assert_array_equal(st.magnetisations(), 2 * s_ref[:R].sum(axis=1).astype(np.int64) - nvars)
+    return st, s_ref, seeds
+
+
+def test_gaussian_couplings_on_a_square_lattice(capi, oracle, exact, monkeypatch):
+    """2-d Edwards-Anderson glass with Gaussian J: degree 4 -> the one-table kernel (slots = 4)."""
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    W, H = 48, 20
+    ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)
+    ej = np.random.default_rng(2024).normal(size=len(ea))
+    _case(capi, oracle, ea, eb, ej, W * H, R=40, T=6, beta=0.9, slots=4)                      # partial last group
+    _case(capi, oracle, ea, eb, ej, W * H, R=64, T=5, beta=np.geomspace(0.1, 3.0, 5), slots=4)  # annealing schedule
+    _case(capi, oracle, ea, eb, ej, W * H, R=3, T=4, beta=0.0, slots=4)
+    _case(capi, oracle, ea, eb, ej, W * H, R=33, T=4, beta=40.0, slots=4)                     # deep quench
+    init = (np.arange(W * H) % 3 == 0).astype(np.uint8)
+    _case(capi, oracle, ea, eb, ej, W * H, R=20, T=4, beta=0.7, initial=init, slots=4)
+    _case(capi, oracle, ea, eb, ej, W * H, R=37, T=5, beta_replica=np.linspace(0.05, 2.5, 37), slots=4)
+
+
+def test_random_graph_with_real_couplings_and_biases(capi, oracle, monkeypatch):
+    """degree up to 7 -> the two-table kernel (slots = 7); isolated sites, a self-loop, a duplicated bond, biases."""
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    rng = np.random.default_rng(8)
+    n = 700
+    ea, eb = _random_graph(rng, n, 1900, 7, skip=9)
+    ea = np.concatenate([ea, [5, ea[3]]]).astype(np.uint64)
+    eb = np.concatenate([eb, [5, eb[3]]]).astype(np.uint64)
+    ej = rng.normal(size=len(ea)) * 0.37
+    h = rng.normal(size=n) * 0.2
+    _case(capi, oracle, ea, eb, ej, n, R=45, T=6, beta=1.1, biases=h, slots=7)
+    _case(capi, oracle, ea, eb, ej, n, R=32, T=5, beta=np.linspace(0.2, 2.0, 5), biases=h, slots=7)
+    _case(capi, oracle, ea, eb, ej, n, R=70, T=4, beta_replica=np.linspace(3.0, 0.1, 70), biases=h, slots=7)
+    st, s_ref, seeds = _case(capi, oracle, ea, eb, ej, n, R=20, T=3, beta=0.5, slots=7)       # no biases
+    # continue the same container: the timestep counter carries on, set_state replaces one replica
+    new = (np.arange(n) % 2).astype(np.uint8)
+    st.set_state(4, new)
+    s_ref[4] = new
+    st.do_time_steps(3, 0.8)
+    _, s2 = oracle.rj_run(ea, eb, ej, n, seeds, 3, betas=[0.8] * 3, states=s_ref, t0=3)
+    np.testing.assert_array_equal(st.states().astype(np.uint8), s2[:20])
+
+
+def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exact):
+    """Lattice.set_individual_bias (lattice.rs:104-127) on a 128 x 128 ferromagnet: from 16 experiments on the real-coupling
+    path serves it (integer couplings quantise exactly: the energies equal the f64 energy of the configuration)."""
+    import py_monte_carlo
+    W = H = 128                                                     # 16 384 sites: above the LDS-resident bound
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    lat = py_monte_carlo.Lattice.from_arrays(ea, eb, ej, seed_gen=9)
+    lat.set_individual_bias(7, -3.0)
+    info = lat.engine_info()
+    assert info["kind"] == "general" and info["real_slots"] == 4
+    R, T, beta = 40, 5, 0.42
+    e, s = lat.run_monte_carlo(beta, T, R)
+    h = np.zeros(W * H)
+    h[7] = -3.0
+    seeds = np.array(lat.make_seeds(R), dtype=np.uint64)
+    e_ref, s_ref = oracle.rj_run(ea, eb, ej, W * H, seeds, T, betas=[beta] * T, biases=h)
+    assert np.array_equal(s, s_ref[:R].astype(bool)) and np.array_equal(e, e_ref)
+    for r in (0, 17, 39):                                                          # K1 against the f64 Hamiltonian
+        assert e[r] == oracle.energy(ea, eb, ej, W * H, s[r].astype(np.uint8), h)
+    # shards that cut a replica group, per-step energies, sampling
+    for cuts in ([(0, 5), (5, 37), (37, 40)], [(0, 16), (16, 40)]):
+        parts = [lat.run_monte_carlo(beta, T, R, replica_range=r) for r in cuts]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), e) and np.array_equal(np.concatenate([p[1] for p in parts]), s)
+    stops = [(0, 0.2), (T, 0.9)]
+    ea_full, sa_full = lat.run_monte_carlo_annealing_and_get_energies(stops, T, R)
+    e_ann, s_ann = lat.run_monte_carlo_annealing(stops, T, R)
+    assert np.array_equal(ea_full[:, -1], e_ann) and np.array_equal(sa_full, s_ann)
+    ea_part, _ = lat.run_monte_carlo_annealing_and_get_energies(stops, T, R, replica_range=(5, 37))
+    assert np.array_equal(ea_part, ea_full[5:37])
+    es, ss = lat.run_monte_carlo_sampling(beta, 6, R, None, 2, 2)
+    assert es.shape == (R, 3) and ss.shape == (R, 3, W * H)
+    _, s_t4 = oracle.rj_run(ea, eb, ej, W * H, seeds, 4, betas=[beta] * 4, biases=h)
+    assert np.array_equal(ss[:, 0], s_t4[:R].astype(bool))
+    for r in (1, 22):
+        assert es[r, 0] == oracle.energy(ea, eb, ej, W * H, ss[r, 0].astype(np.uint8), h)
+    # below 16 experiments the same inputs run on the f64 CSR path: a different (equally valid) chain
+    e3, s3 = lat.run_monte_carlo(beta, T, 3)
+    e3_ref = [oracle.gen_run(ea, eb, ej, W * H, int(sd), [beta] * T, biases=h)[0] for sd in lat.make_seeds(3)]
+    np.testing.assert_allclose(e3, e3_ref, rtol=1e-12)
+
+
+def test_per_replica_betas_on_any_shard(capi, oracle, exact, monkeypatch):
+    """The real-coupling path decides every replica on its own (no ties numbered over a group): per-replica betas work on a
+    shard that starts and ends inside a group, and the union of the shards is the unsharded run."""
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    ea, eb, _ = exact.square_lattice_edges(20, 12, 1.0)
+    rng = np.random.default_rng(5)
+    ej = rng.normal(size=len(ea))
+    R, T = 70, 4
+    betas = np.linspace(0.1, 1.5, R)
+    seeds = capi.make_seeds(13, R)
+    g = capi.Graph(ea, eb, ej, nvars=240)
+    _, s_ref = oracle.rj_run(ea, eb, ej, 240, seeds, T, beta_replica=betas)
+    got = []
+    for lo, hi in [(0, 7), (7, 45), (45, 70)]:
+        st = capi.States(g, seeds, replica_range=(lo, hi))
+        st.set_betas(betas[lo:hi])
+        st.do_time_steps(T)
+        got.append(st.states().astype(np.uint8))
+    np.testing.assert_array_equal(np.concatenate(got), s_ref[:R])
+
+
+def test_k2_boltzmann_averages_on_the_gpu(capi, oracle, exact, monkeypatch):
+    """K2 for the new kernels: 16 spins, Gaussian couplings and biases, exact enumeration; 3 sigma."""
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    rng = np.random.default_rng(17)
+    n = 16
+    ea, eb = _random_graph(rng, n, 30, 6)
+    ej, h = rng.normal(size=len(ea)), rng.normal(size=n) * 0.4
+    beta = 0.55
+    ex = exact.enumerate_graph(ea, eb, ej, n, beta, h)
+    R = 256
+    g = capi.Graph(ea, eb, ej, nvars=n, biases=h)
+    st = capi.States(g, capi.make_seeds(3, R))
+    st.do_time_steps(200, beta)
+    eps = st.do_time_steps(4000, beta, per_step_energies=True)
+    m = eps.mean(axis=1)
+    z = (m.mean() - ex["E"]) / (m.std(ddof=1) / np.sqrt(R))
+    assert abs(z) < 3.0, (z, m.mean(), ex["E"])
+    mags = []
+    for _ in range(200):
+        st.do_time_steps(5, beta)
+        mags.append(np.abs(st.magnetisations()))
+    mm = np.mean(mags, axis=0)
+    zm = (mm.mean() - ex["absM"]) / (mm.std(ddof=1) / np.sqrt(R))
+    assert abs(zm) < 3.0, (zm, mm.mean(), ex["absM"])
