@@ -96,23 +96,29 @@ def _profile_json(name):
 
 
 def traffic_from_profile():
-    """HBM bytes per colour half-sweep (all replicas) from the committed rocprofv3 --pmc passes, or None."""
+    """HBM bytes per colour half-sweep (all replicas) from the committed rocprofv3 --pmc passes, or None.
+    NOT measured in this run: counters need their own rocprofv3 passes (tools/profile.sh)."""
     d = _profile_json("traffic_latest.json")
     return d.get("hbm_bytes_per_launch") if d else None
 
 
 def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
     """Secondary roofline: the sweep kernel is bound by vector-ALU issue cycles, not by HBM.
-    achieved = VALU-busy SIMD cycles per quad (SQ counters of the same kernel, committed under profiles/);
-    peak = SIMD cycles a wave of quads owns = launch time x live shader clock x SIMDs / wave-quads per launch."""
+    achieved = VALU-busy SIMD cycles per wave of quads from the SQ counters of the same kernel -- a COMMITTED profile
+    (profiles/sq_latest.json: another session, possibly another box), lane-weighted, so an estimate;
+    peak = SIMD cycles a wave of quads owns in THIS run = launch time x live shader clock x SIMDs / wave-quads per launch.
+    The two terms come from different sessions: the ratio is reported as an estimate and clamped to 1 (a kernel cannot be
+    busier than the cycles it owns; raw_ratio keeps what the division gave, saturated says it was clamped)."""
     d = _profile_json("sq_latest.json")
     if not d or not clock_ghz:
         return None
     owned = avg_launch_us * 1e-6 * clock_ghz * 1e9 * N_CU * SIMD_PER_CU / quads_per_launch
     busy = d["valu_busy_cycles_per_quad"]
+    raw = busy / owned
     return {"bound": "valu", "achieved": busy, "peak": owned, "unit": "SIMD cycles per wave of 64 quads (8192 spins)",
-            "frac": busy / owned, "clock_ghz": clock_ghz, "valu_insts_per_quad": d.get("valu_insts_per_quad"),
-            "source": d.get("source")}
+            "frac": min(1.0, raw), "raw_ratio": raw, "saturated": raw >= 1.0, "kind": "profile-derived estimate",
+            "clock_ghz": clock_ghz, "valu_insts_per_quad": d.get("valu_insts_per_quad"),
+            "achieved_source": d.get("source"), "peak_source": "this run: HIP-event launch time x live shader clock"}
 
 
 def main():
@@ -193,6 +199,7 @@ def main():
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(),
+                    "traffic_source": "profiles/traffic_latest.json (committed rocprofv3 --pmc passes, not measured in this run)",
                     "kernel": "lat_sweep_loop_kernel<uniformJ> (2 quads per thread; replicas in 2 stream lanes)",
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_launch_us,

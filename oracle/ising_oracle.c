@@ -260,6 +260,50 @@ void orc_ref_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const d
 }
 
 /*
+ * Equilibrium averages of engine A for the observables table (tests/observables.py): per chain, `therm` timesteps at beta,
+ * then `steps` timesteps during which the energy (updated incrementally by the accepted dE) and |M| are accumulated after
+ * every timestep.  mean_e_out / mean_absm_out: double[R].
+ */
+void orc_ref_averages(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                      const double *biases, const uint64_t *seeds, size_t R, const uint8_t *initial, double beta,
+                      size_t therm, size_t steps, double *mean_e_out, double *mean_absm_out)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t r = 0; r < R; r++) {
+        uint8_t *state = malloc(nvars ? nvars : 1);
+        xoshiro g;
+        xo_seed_from_u64(&g, seeds[r]);
+        if (initial) memcpy(state, initial, nvars);
+        else for (size_t i = 0; i < nvars; i++) state[i] = (uint8_t)xo_bool(&g);
+        double e = orc_energy(n_edges, ea, eb, ej, nvars, biases, state), sum_e = 0.0, sum_m = 0.0;
+        int64_t m = 0;
+        for (size_t i = 0; i < nvars; i++) m += state[i] ? 1 : -1;
+        for (size_t t = 0; t < therm + steps; t++) {
+            for (size_t a = 0; a < nvars; a++) {
+                size_t i = (size_t)xo_below(&g, nvars);
+                double si = state[i] ? 1.0 : -1.0;
+                double field = 0.0;
+                for (size_t k = A.ptr[i]; k < A.ptr[i + 1]; k++)
+                    field += A.w[k] * (state[A.nbr[k]] ? 1.0 : -1.0);
+                double dE = 2.0 * si * ((biases ? biases[i] : 0.0) - field);
+                if (dE <= 0.0 || xo_f64(&g) < exp(-beta * dE)) {
+                    state[i] = !state[i];
+                    e += dE;
+                    m += state[i] ? 2 : -2;
+                }
+            }
+            if (t >= therm) { sum_e += e; sum_m += (double)(m < 0 ? -m : m); }
+        }
+        mean_e_out[r] = steps ? sum_e / (double)steps : e;
+        mean_absm_out[r] = steps ? sum_m / (double)steps : (double)(m < 0 ? -m : m);
+        free(state);
+    }
+    adj_free(&A);
+}
+
+/*
  * Timed variant for bench.py's cpu_baseline leg: the same R chains on `threads` OpenMP threads,
  * constant beta, no outputs kept; *seconds_out = wall time of the sweep loop only (adjacency
  * construction and the random start are excluded, as on the GPU side).  Returns a checksum of the

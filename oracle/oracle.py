@@ -38,6 +38,8 @@ def lib():
         L.orc_ref_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p,
                                   C.c_size_t, C.c_void_p, f64p, C.c_size_t, u8p, C.c_void_p,
                                   C.c_void_p]
+        L.orc_ref_averages.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p, C.c_size_t, C.c_void_p,
+                                       C.c_double, C.c_size_t, C.c_size_t, f64p, f64p]
         L.orc_ref_bench.restype = C.c_uint64
         L.orc_ref_bench.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, u64p, C.c_size_t,
                                     C.c_double, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
@@ -140,6 +142,16 @@ def ref_run(ea, eb, ej, nvars, seeds, betas, biases=None, initial=None, per_step
     lib().orc_ref_run(len(ea), ea, eb, ej, nvars, _ptr(b), seeds, R, _ptr(ini), betas, T, states,
                       _ptr(energies), _ptr(eps))
     return (energies, states, eps) if per_step else (energies, states)
+
+
+def ref_averages(ea, eb, ej, nvars, seeds, beta, therm, steps, biases=None, initial=None):
+    """(mean E, mean |M|) per chain of engine A: `therm` timesteps, then averages over `steps` timesteps."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    ini = None if initial is None else np.ascontiguousarray(initial, dtype=np.uint8)
+    e, m = np.zeros(len(seeds)), np.zeros(len(seeds))
+    lib().orc_ref_averages(len(ea), ea, eb, ej, nvars, _ptr(b), seeds, len(seeds), _ptr(ini), float(beta), therm, steps, e, m)
+    return e, m
 
 
 def ref_bench(ea, eb, ej, nvars, seeds, beta, timesteps, threads):

@@ -161,7 +161,7 @@ def recognise_lattice2d(ea, eb, ej, nvars):
     _check(lib().isingmc_host_recognise_lattice2d(_p(ea), _p(eb), _p(ej), len(ea), nvars, C.byref(ok), C.byref(w),
                                                   C.byref(h), C.byref(jabs), C.byref(u)))
     out = dict(is_lattice=bool(ok.value), width=w.value, height=h.value, jabs=jabs.value, uniform_sign=bool(u.value))
-    if (ok.value - 1) & 6 > 0:  # open boundaries (all wrap-around bonds of a direction absent)
+    if ok.value > 0 and (ok.value - 1) & 6:  # open boundaries (all wrap-around bonds of a direction absent)
         out.update(open_x=bool((ok.value - 1) & 2), open_y=bool((ok.value - 1) & 4))
     if ok.value > 0 and (ok.value - 1) & 8:  # jabs is the horizontal bonds' |J|, the vertical bonds have another
         out.update(anisotropic=True)

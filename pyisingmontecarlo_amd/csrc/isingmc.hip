@@ -144,6 +144,10 @@ struct isingmc_states {
     unsigned long long *d_pt_mail = nullptr, *d_pt_round_counts = nullptr; // in-kernel exchange rounds (StripLadder)
     uint32_t *d_pt_perm2 = nullptr;
     unsigned long long *d_strip_fin = nullptr; // [cap] final-measurement counters of the strip kernel (zero between launches)
+    bool strip_test_failed = false; // ISINGMC_STRIP_TEST_FAIL_ONCE has fired for this object
+    bool strip_disabled = false;    // a strip launch of this object timed out once: the per-colour launches serve it from then on
+    uint32_t *d_snapshot = nullptr; // the planes a synchronous call started from (restored when a strip launch gives up)
+    size_t snapshot_cap = 0;
     bool meas_fresh = false; // the tempering send buffer holds the energies of the CURRENT configurations (written by the last strip launch)
     // sampling pipeline (isingmc_run_sampling): two slabs of samples in flight
     hipStream_t copy_stream = nullptr;
@@ -185,6 +189,7 @@ struct isingmc_states {
         if (d_halo) (void)hipFree(d_halo);
         if (d_strip_err) (void)hipFree(d_strip_err);
         if (d_strip_fin) (void)hipFree(d_strip_fin);
+        if (d_snapshot) (void)hipFree(d_snapshot);
         for (void *p : {(void *)d_pt_mail, (void *)d_pt_round_counts, (void *)d_pt_perm2})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
@@ -1033,6 +1038,10 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
     for (size_t r = 0; r < s->R; r++)
         if (!std::isfinite(beta_per_replica[r])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
+    if (!all_equal) { // one beta R times is as good as a uniform beta: any cut of a group is fine then
+        all_equal = true;
+        for (size_t r = 1; r < s->R; r++) all_equal &= beta_per_replica[r] == beta_per_replica[0];
+    }
     if (s->packed && !s->rj && !all_equal && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
         // the replicas of a group number their ties together: a group's trajectory depends on all 32 betas, and this
         // shard only knows its own (the real-coupling path decides every replica on its own: any cut is fine there)
@@ -1241,7 +1250,7 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
 // energy of one replica of a packed container from the first counter of its slot
 static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0)
 {
-    // real-coupling path: c0 = sum_i (X_i + s_i hq_i) = -2 x the energy in units of 2^k (an exact integer)
+    // real-coupling path: c0 = -2 x the energy in units of 2^k (an exact, even integer; rj_measure_kernel)
     if (rj) return std::ldexp(double(-(int64_t(c0) / 2)), g->rj_k) + g->self_energy;
     // bit-sliced path: E = |J| (undirected bonds - 2 satisfied) + self loops; c0 = directed satisfied count (doubled)
     return g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(c0))) + g->self_energy;
@@ -1592,12 +1601,26 @@ struct StripPlan {
 // Mid-size lattices only: a per-colour launch of the streaming kernel must be short enough for the ~5 us it loses
 // between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups in all, default the resident limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
 // half-sweep must fit one workgroup (2 rows of <= 128 words).  ISINGMC_STRIP=0 disables, =1 forces (tests, A/B runs).
-static StripPlan strip_plan(const isingmc_states *s, size_t timesteps)
+// resident workgroups per CU, cached per instantiation and LDS size (the occupancy query is a runtime call)
+static int strip_resident_blocks_per_cu(bool pmj, int nw, bool ladder, size_t lds)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<uint64_t, int>> cache;
+    const uint64_t key = (uint64_t(lds) << 8) | (uint64_t(pmj) << 2) | (uint64_t(ladder) << 1) | uint64_t(nw == 1);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &e : cache)
+        if (e.first == key) return e.second;
+    const int n = strip_blocks_per_cu(pmj, nw, ladder, lds);
+    cache.emplace_back(key, n);
+    return n;
+}
+
+static StripPlan strip_plan(const isingmc_states *s, size_t timesteps, bool ladder = false)
 {
     StripPlan P;
     const isingmc_graph *g = s->g;
     const int mode = env_int("ISINGMC_STRIP", -1);
-    if (mode == 0 || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
+    if (mode == 0 || s->strip_disabled || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
     const uint32_t qpr = g->geom.wpr / 4;
     if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, at least two rows per wave
     P.nw = env_int("ISINGMC_STRIP_NW", 4) == 1 ? 1 : 4; // measured on 1024^2 x 64: 9.6 us per timestep either way; with exchange rounds 11.5 (4) / 12.0 (1)
@@ -1605,9 +1628,15 @@ static StripPlan strip_plan(const isingmc_states *s, size_t timesteps)
     if (g->geom.H % S != 0 || g->geom.H / S < 2) return P;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
-    const size_t limit = size_t(STRIP_MAX_WAVES_PER_CU) * size_t(std::max(dev_cus, 1)) / size_t(P.nw); // workgroups resident at once
+    // Every workgroup of a launch must be resident at once.  Per CU: what the runtime's occupancy calculation grants this
+    // instantiation with its dynamic LDS (registers, LDS, wave slots), and never more than the policy bound of
+    // STRIP_MAX_WAVES_PER_CU waves (beyond it the per-colour launches are faster anyway).
+    const size_t lds = (size_t(2) * (S + 2) * g->geom.wpr + 16) * sizeof(uint32_t);
+    const int by_occupancy = strip_resident_blocks_per_cu(!g->uniform_sign, P.nw, ladder, lds);
+    const size_t per_cu = std::min<size_t>(size_t(STRIP_MAX_WAVES_PER_CU) / size_t(P.nw), size_t(std::max(by_occupancy, 0)));
+    const size_t limit = per_cu * size_t(std::max(dev_cus, 1)); // workgroups resident at once
     const size_t n_strips = g->geom.H / S, total = s->R * n_strips;
-    if (n_strips > limit) return P;
+    if (limit == 0 || n_strips > limit) return P;
     // one pass only by default: with twice the replicas (1024^2 x 128) the per-colour launches are long enough to win (16.7 vs 18.6 us)
     if (mode != 1 && total > size_t(env_int("ISINGMC_STRIP_MAX_WG", int(limit)))) return P;
     const size_t passes = (total + limit - 1) / limit;
@@ -1658,6 +1687,15 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
         HIP_TRY(hipMemsetAsync(s->d_halo, 0, s->halo_cap * sizeof(unsigned long long), s->stream));
         s->strip_epoch = 0;
     }
+    // test hook (tests/test_gpu_strip.py): the first strip launch of this object runs with the error word already raised,
+    // as if a workgroup had timed out -- in-order dispatch makes a real timeout need a co-tenant or a replica of more strips
+    // than the chip holds -- so that the host's recovery (restore the planes, repeat on the per-colour launches) is exercised
+    if (!s->strip_test_failed && env_flag("ISINGMC_STRIP_TEST_FAIL_ONCE")) {
+        const uint32_t one = STRIP_ERR_TIMEOUT;
+        HIP_TRY(hipMemcpyAsync(s->d_strip_err, &one, sizeof one, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->strip_test_failed = true;
+    }
     StripArgs a = P.a;
     a.epoch = s->strip_epoch;
     a.xcd_remap = n % 8 == 0;
@@ -1676,7 +1714,10 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
     return ISINGMC_OK;
 }
 
-// after a synchronisation: did a strip launch give up (its workgroups were not all resident)?
+// after a synchronisation: did a strip launch give up (its workgroups were not all resident)?  Then everything the strip
+// kernels share between launches is reset and the object takes the per-colour launches from now on.  Callers that kept
+// the planes they started from (run_steps, isingmc_run_sampling) repeat their work; the others report the error.
+constexpr int STRIP_TIMED_OUT = 1000; // internal status, never returned through the C ABI
 static int strip_check(isingmc_states *s)
 {
     if (!s->d_strip_err) return ISINGMC_OK;
@@ -1685,13 +1726,78 @@ static int strip_check(isingmc_states *s)
     if (h == 0) return ISINGMC_OK;
     (void)hipMemset(s->d_strip_err, 0, sizeof h);
     if (s->d_strip_fin) (void)hipMemset(s->d_strip_fin, 0, s->cap * sizeof(unsigned long long));
+    if (s->d_pt_round_counts) (void)hipMemset(s->d_pt_round_counts, 0, 2 * s->R * sizeof(unsigned long long));
+    if (s->d_pt_mail) (void)hipMemset(s->d_pt_mail, 0, 4 * s->R * sizeof(unsigned long long));
+    if (s->d_halo) (void)hipMemset(s->d_halo, 0, s->halo_cap * sizeof(unsigned long long));
+    s->strip_epoch = 0;
+    s->meas_fresh = false;
+    s->strip_disabled = true;
+    return STRIP_TIMED_OUT;
+}
+
+static int strip_error(int rc)
+{
+    if (rc != STRIP_TIMED_OUT) return rc;
     return fail(ISINGMC_ERR_HIP, "the persistent strip kernel timed out waiting for a neighbour strip (its workgroups were not all "
-                                 "resident: is another process using this GPU?); the configurations of this object are invalid. "
-                                 "ISINGMC_STRIP=0 selects the per-colour launches");
+                                 "resident: is another process using this GPU?) inside a sequence of enqueue-only calls; the "
+                                 "configurations of this object are invalid.  The object uses the per-colour launches from now on "
+                                 "(ISINGMC_STRIP=0 selects them from the start)");
+}
+
+static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride, double *energies_per_step,
+                          float *device_ms, bool sync, double *final_energies);
+
+// planes of a states object before a call that may launch the strip kernel (D2D copy on the engine's stream: ~3 us for
+// 1024^2 x 64), so that a timeout costs a repeat of the call instead of the configurations
+static int snapshot_take(isingmc_states *s)
+{
+    const size_t words = s->R * s->g->state_words;
+    if (s->snapshot_cap < words) {
+        if (s->d_snapshot) HIP_TRY(hipFree(s->d_snapshot));
+        s->d_snapshot = nullptr;
+        s->snapshot_cap = 0;
+        TRY(dev_alloc(&s->d_snapshot, words));
+        s->snapshot_cap = words;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_snapshot, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    return ISINGMC_OK;
+}
+
+static int snapshot_restore(isingmc_states *s)
+{
+    HIP_TRY(hipMemcpyAsync(s->d_state, s->d_snapshot, s->R * s->g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    return ISINGMC_OK;
+}
+
+static bool may_use_strips(const isingmc_states *s)
+{
+    return s && s->R && !s->packed && !s->strip_disabled && s->g->kind == ISINGMC_KIND_LATTICE2D && s->g->mc_mode == MC_NONE &&
+           env_int("ISINGMC_STRIP", -1) != 0;
 }
 
 static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
                      double *energies_per_step, float *device_ms, bool sync = true, double *final_energies = nullptr)
+{
+    // a synchronous call keeps the planes it started from when it may launch the strip kernel; if a launch gives up (its
+    // workgroups were not all resident: a co-tenant, a CU mask) the call is repeated with the per-colour launches
+    const bool guard = sync && timesteps >= 2 && may_use_strips(s) && strip_plan(s, timesteps).use;
+    if (!guard) {
+        const int rc = run_steps_impl(s, timesteps, betas, beta_stride, energies_per_step, device_ms, sync, final_energies);
+        return sync ? strip_error(rc) : rc;
+    }
+    TRY(use_device(s->g->device));
+    const uint64_t t0 = s->t;
+    TRY(snapshot_take(s));
+    int rc = run_steps_impl(s, timesteps, betas, beta_stride, energies_per_step, device_ms, sync, final_energies);
+    if (rc != STRIP_TIMED_OUT) return rc;
+    TRY(snapshot_restore(s));
+    s->t = t0;
+    rc = run_steps_impl(s, timesteps, betas, beta_stride, energies_per_step, device_ms, sync, final_energies); // strip_disabled now
+    return strip_error(rc);
+}
+
+static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride, double *energies_per_step,
+                          float *device_ms, bool sync, double *final_energies)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (timesteps && !betas && !s->has_betas) return fail(ISINGMC_ERR_INVALID, "betas is NULL");
@@ -2017,9 +2123,10 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
             const size_t nblocks = g->pk.n_pos / 256;
             for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
                 const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
-                const size_t gx = std::min(nblocks, std::max<size_t>(1, (1536 + ng - 1) / ng));
+                // all workgroups resident at once (32 KB of LDS each: 4 per CU), every one walks its share of the blocks
+                const size_t gx = std::min(nblocks, std::max<size_t>(1, (1024 + ng - 1) / ng));
                 HIP_TRY(rj_launch_measure(dim3(unsigned(gx), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj, g->pk.site,
-                                          counts_slot + 2 * 32 * g0));
+                                          g->n_colours == 2 ? uint32_t(g->class_base[1]) : 0u, counts_slot + 2 * 32 * g0));
             }
             return ISINGMC_OK;
         }
@@ -2106,8 +2213,28 @@ static void madvise_hugepages(void *p, size_t bytes)
     if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
 }
 
+static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq, size_t n_samples,
+                             double *energies_out, uint8_t *states_out);
+
 extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq,
                                     size_t n_samples, double *energies_out, uint8_t *states_out)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (!may_use_strips(s) || !(strip_plan(s, thermalization).use || strip_plan(s, sampling_freq).use))
+        return strip_error(run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out));
+    // as run_steps: the call keeps the planes it started from and is repeated without the strip kernel if a launch gives up
+    TRY(use_device(s->g->device));
+    const uint64_t t0 = s->t;
+    TRY(snapshot_take(s));
+    int rc = run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out);
+    if (rc != STRIP_TIMED_OUT) return rc;
+    TRY(snapshot_restore(s));
+    s->t = t0;
+    return strip_error(run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out));
+}
+
+static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq, size_t n_samples,
+                             double *energies_out, uint8_t *states_out)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (sampling_freq == 0) return fail(ISINGMC_ERR_INVALID, "sampling_freq must be positive");
@@ -2212,7 +2339,7 @@ extern "C" int isingmc_synchronize(isingmc_states *s)
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     TRY(use_device(s->g->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return strip_check(s);
+    return strip_error(strip_check(s));
 }
 
 extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
@@ -2295,7 +2422,7 @@ extern "C" int isingmc_pt_run(isingmc_states *s, size_t timesteps, size_t swap_e
     TRY(use_device(s->g->device));
     const isingmc_graph *g = s->g;
     const size_t rounds = timesteps / swap_every, tail = timesteps % swap_every;
-    const StripPlan P = s->R ? strip_plan(s, rounds * swap_every) : StripPlan{};
+    const StripPlan P = s->R ? strip_plan(s, rounds * swap_every, /*ladder=*/true) : StripPlan{};
     const bool in_kernel = P.use && P.replicas_per_pass >= s->R && rounds >= 2 && rounds * swap_every <= 65536 &&
                            s->R == s->pt.n_rungs && env_int("ISINGMC_PT_IN_KERNEL", 1) != 0;
     if (in_kernel) {
@@ -2379,7 +2506,7 @@ extern "C" int isingmc_pt_state(isingmc_states *s, uint32_t *perm_out, uint64_t 
     if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
     TRY(use_device(s->g->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    TRY(strip_check(s));
+    TRY(strip_error(strip_check(s)));
     unsigned long long c[2];
     HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
     if (perm_out) HIP_TRY(hipMemcpy(perm_out, s->d_pt_perm, s->pt.n_rungs * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -11,6 +11,7 @@
 
 #include <cstdlib>
 #include <memory>
+#include <limits>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -488,9 +489,9 @@ public:
     void run_monte_carlo(double beta, size_t timesteps, std::optional<size_t> nspinupdates, std::optional<size_t>,
                          std::optional<size_t>, std::optional<bool>)
     {
-        const size_t mult = sweeps_per_timestep(nspinupdates);
+        const size_t sweeps = sweeps_for(timesteps, nspinupdates);
         py::gil_scoped_release nogil;
-        check(isingmc_do_time_steps(st_->s, timesteps * mult, &beta, 0, nullptr));
+        check(isingmc_do_time_steps(st_->s, sweeps, &beta, 0, nullptr));
     }
 
     // classicising.rs:119-179
@@ -498,16 +499,37 @@ public:
                                        std::optional<size_t>, std::optional<size_t>, std::optional<bool>,
                                        std::optional<size_t> thermalization_time, std::optional<size_t> sampling_freq)
     {
-        const size_t mult = sweeps_per_timestep(nspinupdates);
         const size_t therm = thermalization_time.value_or(0), freq = sampling_freq.value_or(1);
         if (freq == 0) throw py::value_error("sampling_freq must be positive");
         const size_t S = timesteps / freq, R = isingmc_states_count(st_->s), N = E_.nvars;
         py::array_t<double> energies(std::vector<ssize_t>{ssize_t(R), ssize_t(S)});
         py::array_t<bool> states(std::vector<ssize_t>{ssize_t(R), ssize_t(S), ssize_t(N)});
+        if (whole_sweeps(nspinupdates)) { // every timestep is made of whole sweeps: one pipelined library call
+            const size_t mult = nspinupdates ? *nspinupdates / N : 1;
+            double *e_out = energies.mutable_data();
+            uint8_t *s_out = reinterpret_cast<uint8_t *>(states.mutable_data());
+            {
+                py::gil_scoped_release nogil;
+                Lattice::sample_into(st_->s, beta, therm * mult, freq * mult, S, R, N, e_out, s_out);
+            }
+            return py::make_tuple(energies, states);
+        }
+        // attempts per timestep that are not whole sweeps: the blocks between samples hold varying numbers of sweeps
+        std::vector<size_t> block(S + 1);
+        block[0] = sweeps_for(therm, nspinupdates);
+        for (size_t k = 0; k < S; k++) block[k + 1] = sweeps_for(freq, nspinupdates);
+        double *e = energies.mutable_data();
+        uint8_t *st = reinterpret_cast<uint8_t *>(states.mutable_data());
         {
             py::gil_scoped_release nogil;
-            Lattice::sample_into(st_->s, beta, therm * mult, freq * mult, S, R, N, energies.mutable_data(),
-                                 reinterpret_cast<uint8_t *>(states.mutable_data()));
+            std::vector<double> e_k(R);
+            check(isingmc_do_time_steps(st_->s, block[0], &beta, 0, nullptr));
+            for (size_t k = 0; k < S; k++) {
+                check(isingmc_do_time_steps(st_->s, block[k + 1], &beta, 0, nullptr));
+                check(isingmc_get_energies(st_->s, e_k.data()));
+                for (size_t r = 0; r < R; r++) e[r * S + k] = e_k[r];
+                if (R) check(isingmc_get_states(st_->s, st + k * N, S * N)); // replica r's sample k sits at (r S + k) N
+            }
         }
         return py::make_tuple(energies, states);
     }
@@ -528,17 +550,37 @@ public:
     size_t get_num_graphs() const { return isingmc_states_count(st_->s); }
 
 private:
-    // nspinupdates = single-spin attempts per timestep (crate default: nvars).  A sweep is nvars
-    // attempts, so only whole multiples can be honoured.
-    size_t sweeps_per_timestep(const std::optional<size_t> &nspinupdates) const
+    // nspinupdates = single-spin attempts per timestep (classicising.rs:88-110 hands it to do_time_step; crate default:
+    // nvars).  The engine attempts every site once per sweep, in the colour order, so attempts are executed sweep by
+    // sweep: `timesteps` timesteps of n attempts add timesteps x n attempts to a cursor that persists across calls,
+    // every nvars accumulated attempts run as one sweep, and the remainder (< nvars attempts) stays pending for the next
+    // call.  Whole multiples of nvars are exactly that many sweeps per timestep; any other positive count is honoured on
+    // average (the total number of attempts is exact up to the pending remainder), with a one-off warning.
+    bool whole_sweeps(const std::optional<size_t> &nspinupdates) const
     {
-        if (!nspinupdates) return 1;
-        if (*nspinupdates == 0 || *nspinupdates % E_.nvars != 0)
-            throw py::value_error("nspinupdates must be a positive multiple of the number of variables (" +
-                                  std::to_string(E_.nvars) + "): one timestep is made of whole sweeps");
-        return *nspinupdates / E_.nvars;
+        return !nspinupdates || (*nspinupdates > 0 && *nspinupdates % E_.nvars == 0 && pending_attempts_ == 0);
+    }
+    size_t sweeps_for(size_t timesteps, const std::optional<size_t> &nspinupdates)
+    {
+        if (!nspinupdates) return timesteps;
+        if (*nspinupdates == 0) throw py::value_error("nspinupdates must be positive");
+        if (*nspinupdates % E_.nvars != 0 && !warned_partial_) {
+            warned_partial_ = true;
+            if (PyErr_WarnEx(PyExc_UserWarning,
+                             "nspinupdates is not a multiple of the number of variables: attempts are executed sweep by sweep "
+                             "(every site once, in the colour order); the attempts that do not complete a sweep stay pending "
+                             "and count towards the next timesteps", 1) < 0)
+                throw py::error_already_set();
+        }
+        const unsigned __int128 total = (unsigned __int128)timesteps * *nspinupdates + pending_attempts_;
+        const unsigned __int128 sweeps = total / E_.nvars;
+        if (sweeps > (unsigned __int128)std::numeric_limits<size_t>::max() / 4) throw py::value_error("too many spin updates");
+        pending_attempts_ = size_t(total % E_.nvars);
+        return size_t(sweeps);
     }
 
+    size_t pending_attempts_ = 0;
+    bool warned_partial_ = false;
     EdgeArrays E_;
     double longitudinal_;
     bool use_basic_moves_; // stored, never read -- as in the reference (classicising.rs:45,54)

@@ -15,10 +15,12 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
 }
 
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
-                             unsigned long long *out)
+                             uint32_t class0_end, unsigned long long *out)
 {
-    if (G.slots == 4) hipLaunchKernelGGL(rj_measure_kernel<4>, grid, dim3(RJ_THREADS), 0, stream, state, G, site, out);
-    else hipLaunchKernelGGL(rj_measure_kernel<7>, grid, dim3(RJ_THREADS), 0, stream, state, G, site, out);
+    const auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(RJ_THREADS), 0, stream, state, G, site, class0_end, out); };
+    const bool bip = class0_end != 0;
+    if (G.slots == 4) { if (bip) launch(rj_measure_kernel<4, true>); else launch(rj_measure_kernel<4, false>); }
+    else { if (bip) launch(rj_measure_kernel<7, true>); else launch(rj_measure_kernel<7, false>); }
     return hipGetLastError();
 }
 

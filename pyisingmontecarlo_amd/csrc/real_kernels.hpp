@@ -168,11 +168,15 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restri
     }
 }
 
-// sum over the real positions of (X + s hq) and of the up spins, per replica.  A thread walks positions
-// blockIdx.x * 256 + tid, + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
-template <int SLOTS>
+// -2 x (energy in units of 2^k) and the up spins, per replica.  General graphs: sum over the real positions of
+// X + s hq = 2 s hq - s F (every bond is seen from both ends).  BIP (two colour classes: every bond joins class 0 to
+// class 1): the bonds are taken from the class-0 positions only (p < class0_end: 2 X = 2 s hq - 2 s F), the class-1
+// positions add just their bias term 2 s hq -- no gathers, no table there.  A thread walks positions blockIdx.x * 256 + tid,
+// + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
+template <int SLOTS, bool BIP>
 __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *__restrict__ state, const RjGraphDev G,
-                                                                const uint32_t *__restrict__ site, unsigned long long *__restrict__ out)
+                                                                const uint32_t *__restrict__ site, const uint32_t class0_end,
+                                                                unsigned long long *__restrict__ out)
 {
     __shared__ uint32_t s_x[32 * RJ_THREADS];
     const uint32_t tid = threadIdx.x, g = blockIdx.y;
@@ -181,17 +185,30 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *
     uint32_t up[32];
 #pragma unroll
     for (int b = 0; b < 32; b++) { acc[b] = 0; up[b] = 0; }
-    for (uint32_t p = blockIdx.x * RJ_THREADS + tid; p < G.n_pos; p += gridDim.x * RJ_THREADS) {
+    for (uint32_t base = blockIdx.x * RJ_THREADS; base < G.n_pos; base += gridDim.x * RJ_THREADS) { // base: wave-uniform
+        const uint32_t p = base + tid;
         if (site[p] == RJ_PAD_SITE) continue;
+        if (BIP && base >= class0_end) { // class boundaries are multiples of 256: uniform per workgroup
+            const uint32_t own = st[p];
+            const long long h2 = 2ll * G.hq[p];
+#pragma unroll
+            for (int b = 0; b < 32; b++) {
+                const uint32_t bit = (own >> b) & 1u;
+                acc[b] += bit ? h2 : -h2;
+                up[b] += bit;
+            }
+            continue;
+        }
         uint32_t own, w[8];
         int32_t jq[SLOTS], hq;
         rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
-        rj_build_tables<SLOTS, 2, false>(s_x, tid, jq, hq, 0u);
+        rj_build_tables<SLOTS, BIP ? 1 : 2, false>(s_x, tid, jq, hq, 0u);
         rj_transpose(w);
 #pragma unroll
         for (int b = 0; b < 32; b++) {
             const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
-            acc[b] += (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, idx));
+            const long long x = (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, idx));
+            acc[b] += BIP ? 2 * x : x;
             up[b] += (own >> b) & 1u;
         }
     }

@@ -35,10 +35,10 @@ struct RjBeta {
 hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
                            uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride);
 
-// out[2 slot] += sum over the real positions in [0, n_pos) of (X + s hq) (an int64 in two's complement: the energy in units
-// of 2^k is minus half of it), out[2 slot + 1] += up spins; slot = 32 g + b.  class_real_end: device array of the ends of the
-// real sites per colour class is not needed here: padding carries the PAD marker in `site`.
+// out[2 slot] += -2 x (energy of replica slot in units of 2^k, bias terms included) as an int64 in two's complement,
+// out[2 slot + 1] += up spins; slot = 32 g + b.  class0_end: 0, or -- on a graph of exactly two colour classes -- the end
+// of class 0: the bonds are then counted from the class-0 positions alone.  Padding carries the PAD marker in `site`.
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
-                             unsigned long long *out);
+                             uint32_t class0_end, unsigned long long *out);
 
 } // namespace isingmc

@@ -25,4 +25,24 @@ hipError_t strip_launch(bool pmj, int nw, unsigned blocks, size_t lds_bytes, hip
     return hipGetLastError();
 }
 
+// workgroups of this instantiation that one CU holds at once, by the runtime's own occupancy calculation (registers, the
+// launch's dynamic LDS, wave slots); 0 when the query fails
+int strip_blocks_per_cu(bool pmj, int nw, bool ladder, size_t lds_bytes)
+{
+    int n = 0;
+    const auto ask = [&](auto kernel, int threads) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds_bytes) != hipSuccess) n = 0;
+    };
+    const auto pick = [&](auto pmj_c, auto nw_c) {
+        constexpr bool P = decltype(pmj_c)::value;
+        constexpr int N = decltype(nw_c)::value;
+        if (ladder) ask(lat_strip_kernel<P, N, true>, 64 * N);
+        else ask(lat_strip_kernel<P, N, false>, 64 * N);
+    };
+    if (nw == 1) { if (pmj) pick(std::true_type{}, std::integral_constant<int, 1>{}); else pick(std::false_type{}, std::integral_constant<int, 1>{}); }
+    else { if (pmj) pick(std::true_type{}, std::integral_constant<int, 4>{}); else pick(std::false_type{}, std::integral_constant<int, 4>{}); }
+    (void)hipGetLastError();
+    return n;
+}
+
 } // namespace isingmc

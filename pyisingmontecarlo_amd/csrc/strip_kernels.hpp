@@ -297,9 +297,12 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
                     const unsigned long long old = atomicAdd(cnt, mine_add);
                     if ((old >> STRIP_ARRIVAL_SHIFT) + 1 == a.n_strips) {
                         const unsigned long long total = (old + mine_add) & ((1ull << STRIP_ARRIVAL_SHIFT) - 1);
-                        __hip_atomic_store((strip_gu64)cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // before the post: nobody adds again until it has seen the post
+                        // The counter of this parity is next added to two rounds later, by strips that have read this round's post
+                        // first: the reset is ordered before the post (release) and the readers' later adds after their read of the
+                        // post (acquire fence in the exchange below) -- once per replica and round, so the ordering costs nothing
+                        __hip_atomic_store((strip_gu64)cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store((strip_gu64)(lad.mail + size_t(round & 3) * lad.n_rungs + my_rung),
-                                           ((unsigned long long)(uint32_t(round) + 1u) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                           ((unsigned long long)(uint32_t(round) + 1u) << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 if (fin.counts && last_step) {
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
             uint32_t got = 0;
             if (tid == 0) bail = !strip_wait_granule(box + my_rung, want, got, err);
             if (tid == 1 && partner != 0xFFFFFFFFu) bail = !strip_wait_granule(box + partner, want, got, err);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // pairs with the release of the posts read above
             const uint32_t sat_mine = __shfl(got, 0), sat_other = __shfl(got, 1);
             bail = __any(bail) != 0; // (wave 0; the other waves learn it through red[8])
             if (tid == 0) {

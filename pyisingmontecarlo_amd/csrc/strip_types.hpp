@@ -10,7 +10,8 @@ namespace isingmc {
 struct LatGeom;
 struct LatThr;
 
-constexpr uint32_t STRIP_MAX_WAVES_PER_CU = 16;           // residency by grid size alone (Guideline 16: <= 4 blocks of 256 threads)
+constexpr uint32_t STRIP_MAX_WAVES_PER_CU = 16;           // policy bound (<= 4 blocks of 256 threads per CU: above it the per-colour launches win);
+                                                          // the residency bound proper comes from strip_blocks_per_cu()
 constexpr unsigned long long STRIP_TIMEOUT_TICKS = 200000000ull; // 2 s of the 100 MHz counter
 constexpr uint32_t STRIP_ERR_TIMEOUT = 1u;
 constexpr int STRIP_ARRIVAL_SHIFT = 48;                   // final counter word: satisfied bonds | arrived strips << 48
@@ -61,5 +62,8 @@ hipError_t strip_launch(bool pmj, int nw, unsigned blocks, size_t lds_bytes, hip
                         uint32_t thr_stride, const LatThr *thr_replica, const uint32_t *jneg, uint32_t jneg_uniform,
                         unsigned long long *halo, unsigned long long *steps_out, const StripFinal &fin, const StripLadder &lad,
                         uint32_t n_replicas, uint32_t *err);
+
+// resident workgroups per CU of the instantiation (pmj, nw, ladder) at `lds_bytes` of dynamic LDS: hipOccupancyMaxActiveBlocksPerMultiprocessor
+int strip_blocks_per_cu(bool pmj, int nw, bool ladder, size_t lds_bytes);
 
 } // namespace isingmc

@@ -153,8 +153,18 @@ class ClassicalTempering:
             if self._world > 1:
                 import torch
                 import torch.distributed as dist
-                with torch.cuda.stream(self._pt_stream):
-                    dist.all_gather_into_tensor(self._pt_all, self._pt_local, group=self._group)
+                if dist.get_backend(self._group) == "nccl":
+                    with torch.cuda.stream(self._pt_stream):
+                        dist.all_gather_into_tensor(self._pt_all, self._pt_local, group=self._group)
+                else:
+                    # gloo (several ranks rehearsing on one GPU): the same exchange through the host -- wait for the
+                    # measurement, gather on the CPU, put the result where the exchange kernel reads it
+                    self._states.synchronize()
+                    send = self._pt_local.cpu()
+                    recv = torch.empty(self._world * self._per, dtype=torch.float64)
+                    dist.all_gather_into_tensor(recv, send, group=self._group)
+                    self._pt_all.copy_(recv)
+                    torch.cuda.synchronize()
             self._states.pt_swap()
             if need_perm:
                 self._perm = self._states.pt_state()[0]

@@ -171,8 +171,14 @@ def test_replica_range_is_shard_invariant_on_packed_general_graphs(mod, capi, or
     g = capi.Graph(ea, eb, ej)
     seeds = capi.make_seeds(3, R)
     st = capi.States(g, seeds, replica_range=(5, 37))
-    with pytest.raises(ValueError, match="multiple of 32"):
-        st.set_betas(np.full(32, 0.3))
+    with pytest.raises(ValueError, match="multiples of 32"):
+        st.set_betas(np.linspace(0.2, 0.3, 32))
+    # a shard that ENDS inside a group (and not at the last experiment) is refused too -- the foreign bits of the
+    # group would otherwise run at betas this shard does not know
+    with pytest.raises(ValueError, match="multiples of 32"):
+        capi.States(g, seeds, replica_range=(0, 40)).set_betas(np.linspace(0.2, 0.3, 40))
+    tail = capi.States(g, capi.make_seeds(3, 40), replica_range=(32, 40))      # ends at the last experiment: fine
+    tail.set_betas(np.linspace(0.2, 0.3, 8))
     whole = capi.States(g, seeds)
     whole.set_betas(np.linspace(0.1, 1.0, R))
     whole.do_time_steps(3)
@@ -237,14 +243,63 @@ def test_classic_ising_persistent(mod, oracle, exact):
         assert np.array_equal(states[r], olat.unpack(st).astype(bool)) and energies[r] == olat.energy_mag(st)[0]
     e, s = ci.run_monte_carlo_sampling(0.5, 6, None, None, None, None, 2, 2)
     assert e.shape == (3, 3) and s.shape == (3, 3, W * H)
-    with pytest.raises(ValueError, match="multiple"):
-        ci.run_monte_carlo(0.5, 1, nspinupdates=7)
     with pytest.raises(ValueError):
         mod.ClassicIsing([])
+    with pytest.raises(ValueError, match="positive"):
+        ci.run_monte_carlo(0.5, 1, nspinupdates=0)
     field = mod.ClassicIsing(_edges(ea, eb, ej), 0.5, 1, 1)                 # longitudinal field -> general path
     field.run_monte_carlo(0.3, 5)
     e_ref, s_ref = oracle.gen_run(ea, eb, ej, W * H, oracle.make_seeds(1, 1)[0], [0.3] * 5, biases=np.full(W * H, 0.5))
     assert np.array_equal(field.get_states()[0], s_ref.astype(bool))
+
+
+def test_classic_ising_any_nspinupdates(mod, oracle, exact):
+    """classicising.rs:88-110 takes any count of single-spin attempts per timestep.  Attempts are executed sweep by sweep:
+    timesteps x nspinupdates attempts accumulate (across calls), every nvars of them run as one sweep, the rest stays pending."""
+    W, H = 64, 8
+    N = W * H
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    ci = mod.ClassicIsing(_edges(ea, eb, ej), None, 2, 7)
+    seeds = oracle.make_seeds(7, 2)
+    olat = oracle.Lat(W, H)
+    ref = [olat.init(s) for s in seeds]
+    done = [0]
+
+    def advance(sweeps):
+        for r in range(2):
+            for t in range(done[0], done[0] + sweeps):
+                olat.sweep(ref[r], seeds[r], t, 0.5)
+        done[0] += sweeps
+
+    def check():
+        states, energies = ci.get_states(), ci.get_energies()
+        for r in range(2):
+            assert np.array_equal(states[r], olat.unpack(ref[r]).astype(bool)) and energies[r] == olat.energy_mag(ref[r])[0]
+
+    with pytest.warns(UserWarning, match="sweep by sweep"):
+        ci.run_monte_carlo(0.5, 3, nspinupdates=100)        # 300 attempts < 512: nothing runs yet
+    check()
+    ci.run_monte_carlo(0.5, 3, nspinupdates=100)            # 600 attempts: one sweep, 88 pending
+    advance(1)
+    check()
+    ci.run_monte_carlo(0.5, 5, nspinupdates=N + N // 2)     # 88 + 3840 attempts: 7 sweeps, 344 pending
+    advance(7)
+    check()
+    # sampling with attempts that are not whole sweeps: blocks of varying length (pending 344; 2 x 300 per block)
+    e, s = ci.run_monte_carlo_sampling(0.5, 6, 300, None, None, None, 1, 2)
+    assert e.shape == (2, 3) and s.shape == (2, 3, N)
+    pending = 344
+    blocks = []
+    for attempts in (300, 600, 600, 600):                   # thermalisation (1 timestep), then 3 blocks of 2 timesteps
+        pending += attempts
+        blocks.append(pending // N)
+        pending %= N
+    advance(blocks[0])
+    for k in range(3):
+        advance(blocks[k + 1])
+        for r in range(2):
+            assert np.array_equal(s[r, k], olat.unpack(ref[r]).astype(bool)) and e[r, k] == olat.energy_mag(ref[r])[0]
+    check()
 
 
 def _blocked(x, n=16):
@@ -264,8 +319,39 @@ def test_equilibrium_energy_vs_kaufman(capi, exact):
         per_replica = st.do_time_steps(steps, beta, per_step_energies=True).mean(axis=1)
         mean, err = per_replica.mean(), per_replica.std(ddof=1) / math.sqrt(R)
         ref = exact.kaufman_energy(L, L, beta)
-        assert abs(mean - ref) < 4.5 * err, (L, beta, mean, ref, err)
+        assert abs(mean - ref) < 3.0 * err, (L, beta, mean, ref, err)   # within 3 sigma
         assert err < 3e-3 * abs(ref)
+
+
+def test_k2_general_path_vs_exact_enumeration(capi, exact):
+    """K2 on the GPU: the f64 CSR path on a 16-spin random +-J graph with fields against the exact Boltzmann
+    averages (brute-force enumeration): <E> and <|M|> within 3 sigma, sigma from 512 independent replicas."""
+    rng = np.random.default_rng(16)
+    pairs = set()
+    while len(pairs) < 28:
+        a, b = (int(v) for v in rng.integers(0, 16, 2))
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    pairs = sorted(pairs)
+    ea = np.array([p[0] for p in pairs], dtype=np.uint64)
+    eb = np.array([p[1] for p in pairs], dtype=np.uint64)
+    ej = rng.choice([-1.0, 1.0], size=len(pairs))
+    h = rng.choice([-0.5, 0.0, 0.5], size=16)
+    beta, R = 0.5, 512
+    ex = exact.enumerate_graph(ea, eb, ej, 16, beta, h)
+    g = capi.Graph(ea, eb, ej, nvars=16, biases=h)
+    assert g.kind == capi.KIND_GENERAL
+    st = capi.States(g, capi.make_seeds(41, R))
+    st.do_time_steps(200, beta)
+    e = st.do_time_steps(4000, beta, per_step_energies=True).mean(axis=1)
+    mags = []
+    for _ in range(800):
+        st.do_time_steps(5, beta)
+        mags.append(np.abs(st.magnetisations()))
+    m = np.mean(mags, axis=0)
+    for got, want, name in ((e, ex["E"], "E"), (m, ex["absM"], "|M|")):
+        z = (got.mean() - want) / (got.std(ddof=1) / math.sqrt(R))
+        assert abs(z) < 3.0, (name, z, got.mean(), want)
 
 
 def test_observables_vs_reference_faithful_cpu_engine(capi, oracle, exact):
@@ -286,12 +372,12 @@ def test_observables_vs_reference_faithful_cpu_engine(capi, oracle, exact):
     _, _, eps = oracle.ref_run(ea, eb, ej, W * H, oracle.make_seeds(8, 16), [beta] * 4000, per_step=True)
     ce = eps[:, 2000:].mean(axis=1)
     z = (ge.mean() - ce.mean()) / math.sqrt(ge.var(ddof=1) / len(ge) + ce.var(ddof=1) / len(ce))
-    assert abs(z) < 4.5, ("energy", z)
+    assert abs(z) < 3.0, ("energy", z)
     _, finals = oracle.ref_run(ea, eb, ej, W * H, oracle.make_seeds(9, 64), [beta] * 3000)
     cpu_absm = np.abs(2.0 * finals.sum(axis=1) - W * H)
     gpu_absm = np.abs(st.magnetisations()).astype(np.float64)              # end-of-chain samples on both sides
     z = (gpu_absm.mean() - cpu_absm.mean()) / math.sqrt(gpu_absm.var(ddof=1) / 64 + cpu_absm.var(ddof=1) / 64)
-    assert abs(z) < 4.5, ("|M|", z)
+    assert abs(z) < 3.0, ("|M|", z)
     assert abs(gm.mean() - cpu_absm.mean()) < 0.15 * W * H
 
 

@@ -52,3 +52,19 @@ def test_bare_bench_invocation_spawns_its_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and "cpu_baseline" not in rec and -1.6 < rec["energy_per_site"] < 0.0
+
+
+def test_sharded_c3_ladder_matches_the_in_kernel_exchange(tmp_path):
+    """the sharded tempering protocol (one strip launch per round + all-gather + exchange kernel; two
+    gloo ranks sharing this GPU, 2 x 32 rungs of 1024^2) against the single-rank ladder whose rounds run inside the strip
+    launch: same permutation, swap count, energies and configurations."""
+    out = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_gloo_pt_worker.py"), out, "1024", "64", "40"]
+    assert subprocess.call(cmd, env=env, timeout=900) == 0
+    res = [json.load(open(out + f".{r}")) for r in range(2)]
+    for r in res:
+        assert r["perm"] == res[0]["solo_perm"] and r["swaps"] == res[0]["solo_swaps"] > 0
+    assert res[0]["energies"] + res[1]["energies"] == res[0]["solo_energies"]
+    assert [res[0]["checksum"], res[1]["checksum"]] == res[0]["solo_checksums"]

@@ -76,6 +76,70 @@ def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_repl
     assert np.allclose(states.energies(), e_ref, rtol=1e-12, atol=1e-9)
 
 
+@st.composite
+def random_real_graph(draw):
+    """any couplings / biases, degree <= 7: what the real-coupling packed path takes (duplicate bonds and self-loops included)"""
+    n = draw(st.integers(2, 90))
+    m = draw(st.integers(1, 3 * n))
+    rng = np.random.default_rng(draw(st.integers(0, 2 ** 32 - 1)))
+    ea = rng.integers(0, n, m).astype(np.uint64)
+    eb = rng.integers(0, n, m).astype(np.uint64)
+    maxdeg = draw(st.sampled_from([3, 4, 7]))
+    keep, deg = [], np.zeros(n, dtype=int)
+    for k in range(m):
+        a, b = int(ea[k]), int(eb[k])
+        if a == b or (deg[a] < maxdeg and deg[b] < maxdeg):
+            keep.append(k)
+            if a != b:
+                deg[a] += 1; deg[b] += 1
+    if not any(ea[k] != eb[k] for k in keep):
+        keep = [0]; ea[0], eb[0] = 0, 1
+    ea, eb = ea[keep], eb[keep]
+    kind = draw(st.sampled_from(["gauss", "gauss_small", "integers", "halves"]))
+    ej = {"gauss": rng.normal(size=len(ea)), "gauss_small": rng.normal(size=len(ea)) * 1e-3,
+          "integers": rng.integers(1, 4, len(ea)) * rng.choice([-1.0, 1.0], len(ea)),
+          "halves": rng.integers(1, 6, len(ea)) * 0.5 * rng.choice([-1.0, 1.0], len(ea))}[kind]
+    nvars = int(max(ea.max(), eb.max())) + 1 + draw(st.integers(0, 3))
+    scale = float(np.abs(ej).mean())
+    biases = {0: None, 1: rng.normal(size=nvars) * scale, 2: np.full(nvars, 0.7 * scale)}[draw(st.integers(0, 2))]
+    return ea, eb, ej, nvars, biases
+
+
+@settings(max_examples=30 * SCALE, **COMMON)
+@given(g=random_real_graph(), R=st.integers(1, 70), T=st.integers(0, 5), beta=st.sampled_from([0.0, 0.1, 0.5, 2.0, 30.0, -0.4]),
+       per_replica=st.booleans(), per_step=st.booleans(), seed=st.integers(0, 2 ** 64 - 1))
+def test_random_real_coupling_graphs(capi, oracle, g, R, T, beta, per_replica, per_step, seed):
+    """The replica-packed real-coupling path against oracle engine E: spins, energies (exact integer sums
+    scaled by 2^k: bit-equal), energies after every timestep."""
+    ea, eb, ej, nvars, biases = g
+    if not oracle.rj_eligible(ea, eb, ej, nvars, biases):
+        return
+    os.environ["ISINGMC_FORCE_REAL"] = "1"
+    try:
+        scale = float(np.abs(ej).mean())
+        seeds = capi.make_seeds(seed, R)
+        graph = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
+        if graph.info.real_slots == 0:   # one |J| and no biases: the bit-sliced packed path keeps such a graph
+            assert biases is None and len(set(np.abs(ej[ea != eb]))) == 1
+            return
+        assert graph.info.real_slots in (4, 7)
+        states = capi.States(graph, seeds)
+        if per_replica:
+            betas = np.linspace(0.0, 2.0, R) / scale
+            states.set_betas(betas)
+            eps = states.do_time_steps(T, per_step_energies=per_step)
+            e_ref, s_ref, eps_ref = oracle.rj_run(ea, eb, ej, nvars, seeds, T, beta_replica=betas, biases=biases, per_step=True)
+        else:
+            eps = states.do_time_steps(T, beta / scale, per_step_energies=per_step)
+            e_ref, s_ref, eps_ref = oracle.rj_run(ea, eb, ej, nvars, seeds, T, betas=[beta / scale] * T, biases=biases, per_step=True)
+        assert np.array_equal(states.states().astype(np.uint8), s_ref[:R])
+        assert np.array_equal(states.energies(), e_ref)
+        if per_step:
+            assert np.array_equal(eps, eps_ref)
+    finally:
+        os.environ.pop("ISINGMC_FORCE_REAL", None)
+
+
 @settings(max_examples=20 * SCALE, **COMMON)
 @given(wq=st.integers(1, 6), H=st.sampled_from([2, 4, 6, 8, 12, 16, 34]), pm=st.booleans(), R=st.integers(1, 5),
        T=st.integers(0, 5), beta=st.sampled_from([0.0, 0.2, 0.4407, 0.9, 4.0]), jabs=st.sampled_from([1.0, 0.3]),

@@ -114,3 +114,93 @@ def test_on_stream_tempering_on_the_strip_path(capi, exact, monkeypatch):
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+def test_in_kernel_exchange_against_the_oracle_engine(capi, exact, monkeypatch):
+    """the exchange rounds INSIDE the strip launch (lat_strip_kernel<.., LAD = true>: mailboxes, arrival
+    counter, strip_det_exp, relabelling) against the host swap step driven by the CPU oracle engine (the loop of
+    tempering.rs:177-194): permutation, swap count, spins and energies must be equal."""
+    from helpers import OracleLatEngine
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    W, H, G = 1024, 128, 8                                          # two strips of 64 rows per replica
+    edges = exact.square_lattice_edges(W, H, -1.0)
+    monkeypatch.setenv("ISINGMC_STRIP", "1")
+    monkeypatch.setenv("ISINGMC_PT_IN_KERNEL", "1")
+    runs = []
+    for factory in (None, lambda: OracleLatEngine(W, H)):
+        pt = ClassicalTempering(edges, seed=77, engine_factory=factory)
+        for b in np.linspace(0.4400, 0.4403, G):                   # 131 072 spins: rungs this close exchange
+            pt.add_graph(float(b))
+        pt.timesteps(3)
+        pt.timesteps(26, replica_swap_freq=4)                      # 6 exchange rounds (5 inside the launch) + 2 sweeps
+        pt.timesteps(9, replica_swap_freq=3)                       # odd / even pairing continues
+        st = pt._states
+        runs.append((pt.get_permutation(), pt.get_total_swaps(), st.states(), st.energies()))
+    assert runs[0][1] == runs[1][1] > 0
+    for a, b in zip(runs[0], runs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_in_kernel_exchange_at_c3_shape(capi, oracle, exact, monkeypatch):
+    """BASELINE c3's per-GPU share under pytest -- 1024^2 x 64 rungs = 1024 workgroups, the residency
+    limit: exchange rounds inside the launch == one launch per round; swaps happen; K1 on two rungs."""
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    L, G = 1024, 64
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    runs = []
+    for in_kernel in ("1", "0"):
+        monkeypatch.setenv("ISINGMC_PT_IN_KERNEL", in_kernel)
+        pt = ClassicalTempering((ea, eb, ej), seed=5)
+        for b in np.linspace(0.44000, 0.44030, G):
+            pt.add_graph(float(b))
+        pt.timesteps(2)
+        pt.timesteps(40, replica_swap_freq=10)
+        st = pt._states
+        runs.append((pt.get_permutation(), pt.get_total_swaps(), st.packed(), st.energies()))
+    assert runs[0][1] == runs[1][1] > 0
+    for a, b in zip(runs[0], runs[1]):
+        np.testing.assert_array_equal(a, b)
+    states = st.states()
+    for r in (0, 63):                                                              # K1: host recomputation of the energy
+        assert runs[1][3][r] == oracle.energy(ea, eb, ej, L * L, states[r].astype(np.uint8))
+
+
+def test_strip_timeout_is_recovered(capi, oracle, exact, monkeypatch):
+    """when a strip launch gives up (its workgroups were not all resident) a synchronous call repeats its
+    work from the planes it started with, on the per-colour launches, and the object stays usable.  In-order dispatch makes
+    a real timeout need a co-tenant, so the hook raises the kernel's error word before the object's first strip launch."""
+    W, H, R, T = 1024, 256, 12, 5
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(21, R)
+    monkeypatch.setenv("ISINGMC_STRIP", "0")
+    ref = capi.States(g, seeds)
+    ref.do_time_steps(T, 0.45)
+    ref_eps = ref.do_time_steps(3, 0.45, per_step_energies=True)
+    ref_e, ref_s = ref.run_sampling(0.45, 2, 2, 2)
+    monkeypatch.setenv("ISINGMC_STRIP", "1")
+    monkeypatch.setenv("ISINGMC_STRIP_TEST_FAIL_ONCE", "1")
+    st = capi.States(g, seeds)
+    st.do_time_steps(T, 0.45)                        # "times out", is repeated, must not raise
+    eps = st.do_time_steps(3, 0.45, per_step_energies=True)   # the object took the per-colour path for good
+    np.testing.assert_array_equal(eps, ref_eps)
+    e2, s2 = st.run_sampling(0.45, 2, 2, 2)
+    np.testing.assert_array_equal(e2, ref_e)
+    np.testing.assert_array_equal(s2, ref_s)
+    np.testing.assert_array_equal(st.packed(), ref.packed())
+    # the same hook under the sampling call's own guard
+    st2 = capi.States(g, seeds)
+    ref2 = capi.States(g, seeds)
+    monkeypatch.setenv("ISINGMC_STRIP_TEST_FAIL_ONCE", "0")
+    monkeypatch.setenv("ISINGMC_STRIP", "0")
+    e_ref, s_ref = ref2.run_sampling(0.45, 4, 3, 2)
+    monkeypatch.setenv("ISINGMC_STRIP", "1")
+    monkeypatch.setenv("ISINGMC_STRIP_TEST_FAIL_ONCE", "1")
+    e_got, s_got = st2.run_sampling(0.45, 4, 3, 2)
+    np.testing.assert_array_equal(e_got, e_ref)
+    np.testing.assert_array_equal(s_got, s_ref)
+    lat = oracle.Lat(W, H)
+    o = lat.init(seeds[7])
+    for t in range(T + 3 + 2 + 4):
+        lat.sweep(o, seeds[7], t, 0.45)
+    np.testing.assert_array_equal(st.packed()[7], o)

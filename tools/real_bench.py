@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Real-coupling packed path at VERDICT r02's size: 2048^2 Gaussian-J Edwards-Anderson glass x 128 replicas
 (and a few neighbours: one biased site on the 4096^2 ferromagnet, the 3-d Gaussian glass 128^3, per-replica betas, the f64 CSR
-path on the same inputs).  Usage: real_bench.py [steps] [case-substring]"""
+path on the same inputs).  Usage: real_bench.py [steps] [exact case name]"""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ rng = np.random.default_rng(2024)
 
 
 def run(name, ea, eb, ej, n, reps, T, beta=0.8, biases=None, per_replica=False, env=None):
-    if only and only not in name:
+    if only and only != name:
         return
     for k, v in (env or {}).items():
         os.environ[k] = v
