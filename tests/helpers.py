@@ -51,3 +51,58 @@ class OracleLatEngine:
     def make_states(self, seeds, replica_range=None):
         lo, hi = replica_range if replica_range is not None else (0, len(seeds))
         return OracleLatStates(self.lat, seeds[lo:hi])
+
+
+class OracleRjStates:
+    """Oracle engine E (real-coupling packed spec) behind the States interface the tempering host logic uses."""
+
+    def __init__(self, eng, seeds, lo, hi):
+        self.eng, self.all_seeds, self.lo, self.hi = eng, np.asarray(seeds, dtype=np.uint64), lo, hi
+        self.t = 0
+        self.betas = None
+        self.st = None          # uint8[32 G, nvars] of ALL replicas (the oracle simulates whole groups)
+
+    @property
+    def count(self):
+        return self.hi - self.lo
+
+    def set_betas(self, betas):
+        self.betas = None if betas is None else np.asarray(betas, dtype=np.float64)
+
+    def do_time_steps(self, timesteps, beta=None, per_step_energies=False):
+        e = self.eng
+        R = len(self.all_seeds)
+        kw = {}
+        if self.betas is not None:
+            full = np.zeros(R)
+            full[self.lo:self.hi] = self.betas
+            kw["beta_replica"] = full
+        else:
+            kw["betas"] = [beta] * timesteps if np.ndim(beta) == 0 else beta
+        out = O.rj_run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, timesteps, biases=e.biases, states=self.st, t0=self.t,
+                       per_step=per_step_energies, **kw)
+        self.st = out[1]
+        self.t += timesteps
+        return out[2][self.lo:self.hi] if per_step_energies else None
+
+    def energies(self):
+        e = self.eng
+        if self.st is None:
+            self.do_time_steps(0, 0.0)
+        return O.rj_run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, 0, betas=[], biases=e.biases, states=self.st, t0=self.t)[0][self.lo:self.hi]
+
+    def states(self, out=None):
+        res = self.st[self.lo:self.hi].astype(np.bool_)
+        if out is None:
+            return res
+        out[...] = res
+        return out
+
+
+class OracleRjEngine:
+    def __init__(self, ea, eb, ej, nvars, biases=None):
+        self.ea, self.eb, self.ej, self.nvars, self.biases = ea, eb, ej, nvars, biases
+
+    def make_states(self, seeds, replica_range=None):
+        lo, hi = replica_range if replica_range is not None else (0, len(seeds))
+        return OracleRjStates(self, seeds, lo, hi)

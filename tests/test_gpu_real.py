@@ -169,3 +169,26 @@ def test_k2_boltzmann_averages_on_the_gpu(capi, oracle, exact, monkeypatch):
     mm = np.mean(mags, axis=0)
     zm = (mm.mean() - ex["absM"]) / (mm.std(ddof=1) / np.sqrt(R))
     assert abs(zm) < 3.0, (zm, mm.mean(), ex["absM"])
+
+
+def test_tempering_on_the_real_coupling_path(capi, oracle, exact, monkeypatch):
+    """Parallel tempering of a Gaussian glass -- the use the per-replica acceptance scales exist for: the classical ladder
+    (host swap step, tempering.rs:172-212's loop) on the HIP path against the same host logic driven by oracle engine E."""
+    from helpers import OracleRjEngine
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    W, H, G = 24, 16, 20
+    ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)
+    ej = np.random.default_rng(11).normal(size=len(ea))
+    runs = []
+    for factory in (None, lambda: OracleRjEngine(ea, eb, ej, W * H)):
+        pt = ClassicalTempering((ea, eb, ej), seed=5, engine_factory=factory)
+        for b in np.linspace(0.3, 1.4, G):
+            pt.add_graph(float(b))
+        pt.timesteps(4)
+        pt.timesteps(12, replica_swap_freq=3)
+        states, energies = pt.timesteps_sample(12, replica_swap_freq=2, sampling_freq=4)
+        runs.append((states, energies, pt.get_permutation(), pt.get_total_swaps()))
+    assert runs[0][3] == runs[1][3] > 0
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)

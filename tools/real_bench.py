@@ -18,7 +18,7 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 rng = np.random.default_rng(2024)
 
 
-def run(name, ea, eb, ej, n, reps, T, beta=0.8, biases=None, per_replica=False, env=None):
+def run(name, ea, eb, ej, n, reps, T, beta=0.8, biases=None, per_replica=False, env=None, per_step=False):
     if only and only != name:
         return
     for k, v in (env or {}).items():
@@ -30,8 +30,15 @@ def run(name, ea, eb, ej, n, reps, T, beta=0.8, biases=None, per_replica=False, 
     st.do_time_steps(3, None if per_replica else beta)
     ms = min(st.do_time_steps_timed(T, beta) for _ in range(2))
     rate = reps * n * T / (ms * 1e-3)
-    print(json.dumps({"case": name, "kind": g.kind, "real_slots": g.info.real_slots, "replicas": reps, "sites": n, "steps": T,
-                      "attempts_per_s": rate, "us_per_step": ms / T * 1e3, "e_per_site": float(st.energies().mean() / n)}), flush=True)
+    rec = {"case": name, "kind": g.kind, "real_slots": g.info.real_slots, "replicas": reps, "sites": n, "steps": T,
+           "attempts_per_s": rate, "us_per_step": ms / T * 1e3, "e_per_site": float(st.energies().mean() / n)}
+    if per_step:  # energies after every timestep (lattice.rs:445-455): host clock around the blocking call
+        import time
+        st.do_time_steps(2, beta, per_step_energies=True)
+        t0 = time.perf_counter()
+        st.do_time_steps(T, beta, per_step_energies=True)
+        rec["us_per_step_with_energies"] = (time.perf_counter() - t0) / T * 1e6
+    print(json.dumps(rec), flush=True)
     for k in (env or {}):
         del os.environ[k]
 
@@ -39,7 +46,7 @@ def run(name, ea, eb, ej, n, reps, T, beta=0.8, biases=None, per_replica=False, 
 L = 2048
 ea, eb, _ = square(L, L)
 ej = rng.normal(size=len(ea))
-run("2048^2 gaussian x128", ea, eb, ej, L * L, 128, steps)
+run("2048^2 gaussian x128", ea, eb, ej, L * L, 128, steps, per_step=True)
 run("2048^2 gaussian x128 per-replica betas", ea, eb, ej, L * L, 128, steps, per_replica=True)
 run("2048^2 gaussian x32", ea, eb, ej, L * L, 32, steps)
 run("2048^2 gaussian x16 f64 CSR path", ea, eb, ej, L * L, 16, max(2, steps // 10), env={"ISINGMC_DISABLE_REAL": "1"})
