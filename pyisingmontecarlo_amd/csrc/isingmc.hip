@@ -869,6 +869,7 @@ static int choose_packed(const isingmc_graph *g, size_t n_replicas);
 static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state);
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
 static int pk_set_betas(isingmc_states *s);
+static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state);
 
 // random start for replicas [first, first+count)
 static int init_random(isingmc_states *s, size_t first, size_t count)
@@ -999,8 +1000,8 @@ extern "C" int isingmc_states_append(isingmc_states *s, uint64_t seed, const uin
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (s->has_betas) return fail(ISINGMC_ERR_INVALID, "clear the per-replica betas before appending replicas");
-    if (s->packed) return fail(ISINGMC_ERR_INVALID, "replica-packed states cannot grow: create them with all experiments");
     TRY(use_device(s->g->device));
+    if (s->packed) return pk_append(s, seed, initial_state);
     return add_replicas(s, 1, &seed, initial_state);
 }
 
@@ -1162,6 +1163,49 @@ static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first,
     return ISINGMC_OK;
 }
 
+// ClassicIsing.add_graph (classicising.rs:62-79) on a replica-packed container.  A group simulates all of its 32 bit
+// positions from the moment it is created (the spec numbers ties / draws words over whole groups), so a replica appended
+// into a partly filled group takes over the chain its bit position has been running since then -- a configuration
+// evolved under the same dynamics, i.e. as good a start as a fresh random one, and what the oracle engines give for the
+// final replica count; with an initial_state it is set explicitly.  Replica 32 g opens a new group keyed by its seed,
+// randomly started now.  Only whole containers grow (not shards of a larger set of experiments).
+static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state)
+{
+    const isingmc_graph *g = s->g;
+    if (s->first != 0 || s->n_total != s->R) return fail(ISINGMC_ERR_INVALID, "a shard of a larger set of experiments cannot grow");
+    const size_t slot = s->R;
+    if (slot % 32 == 0) { // a new group
+        const size_t groups = s->groups + 1;
+        uint32_t *d_state = nullptr;
+        uint2 *d_keys = nullptr;
+        unsigned long long *d_meas = nullptr;
+        TRY(dev_alloc(&d_state, groups * g->pk.n_pos));
+        struct Undo { void *a, **b, **c; bool armed = true; ~Undo() { if (armed) { (void)hipFree(a); if (*b) (void)hipFree(*b); if (*c) (void)hipFree(*c); } } }
+            undo{d_state, reinterpret_cast<void **>(&d_keys), reinterpret_cast<void **>(&d_meas)};
+        TRY(dev_alloc(&d_keys, groups));
+        TRY(dev_alloc(&d_meas, 2 * 32 * groups));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(d_state, s->d_state, s->groups * g->pk.n_pos * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->groups * sizeof(uint2), hipMemcpyDeviceToDevice));
+        const uint2 key = make_uint2(uint32_t(seed), uint32_t(seed >> 32));
+        HIP_TRY(hipMemcpy(d_keys + s->groups, &key, sizeof key, hipMemcpyHostToDevice));
+        undo.armed = false;
+        (void)hipFree(s->d_state); (void)hipFree(s->d_keys); (void)hipFree(s->d_meas);
+        s->d_state = d_state; s->d_keys = d_keys; s->d_meas = d_meas;
+        s->meas_zero = false;
+        if (s->d_tab) { (void)hipFree(s->d_tab); s->d_tab = nullptr; }             // per-group tables: rebuilt by the next set_betas
+        if (s->d_rj_betas) { (void)hipFree(s->d_rj_betas); s->d_rj_betas = nullptr; }
+        hipLaunchKernelGGL(pk_init_kernel, dim3((g->pk.n_pos + 255) / 256, 1), dim3(256), 0, s->stream, s->d_state, g->pk, s->d_keys,
+                           uint32_t(s->groups));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->groups = groups;
+    }
+    s->R = s->cap = s->n_total = slot + 1;
+    if (initial_state) TRY(pk_set_state(s, slot, initial_state));
+    return ISINGMC_OK;
+}
+
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins)
 {
     const isingmc_graph *g = s->g;
@@ -1245,7 +1289,7 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
     }
 }
 
-static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot);
+static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up = true);
 
 // energy of one replica of a packed container from the first counter of its slot
 static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0)
@@ -1260,7 +1304,7 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
-    TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr));
+    TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/mags != nullptr));
     s->meas_zero = false;
     std::vector<unsigned long long> h(2 * s->pk_slots());
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_meas, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -1317,7 +1361,7 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
             else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
             s->t++;
-            if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * CS * 2, nullptr, nullptr);
+            if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * CS * 2, nullptr, nullptr, /*want_up=*/false);
         }
         if (energies_per_step && rc == ISINGMC_OK) {
             HIP_TRY(hipMemcpyAsync(h_step_counts.data(), d_step_counts, nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -2113,20 +2157,31 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
 // the packed configurations into a sample ring, the measurement kernels -- and the host only waits once
 // per chunk of samples (<= 512 MiB of packed states), then expands the bits to bools on its threads.
 // ------------------------------------------------------------------------------------------------
-static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot)
+static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up)
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
     if (s->packed) { // counts_slot: [pk_slots()][2], one pair per (group, bit) -- a shard may own only some bits of a group
         HIP_TRY(hipMemsetAsync(counts_slot, 0, 2 * s->pk_slots() * sizeof(unsigned long long), s->stream));
         if (s->rj) {
-            const size_t nblocks = g->pk.n_pos / 256;
+            const bool bip = g->n_colours == 2;
+            int dev_cus = 256;
+            (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
+            // all workgroups resident at once (the runtime's occupancy figure for this instantiation), every one walks its
+            // share of the blocks; a grid one round and a bit long would run its tail at a fraction of the chip
+            static int per_cu[2][2][2] = {};
+            int &pc = per_cu[g->rj.slots == 7][bip][want_up];
+            if (pc == 0) pc = std::max(1, rj_measure_blocks_per_cu(g->rj.slots, bip, want_up));
+            const size_t resident = size_t(pc) * size_t(std::max(dev_cus, 1));
+            // two colour classes: the bonds from class 0 alone; class 1 is visited only for its bias terms or the up spins
+            const uint32_t class0_end = bip ? uint32_t(g->class_base[1]) : 0u;
+            const uint32_t scan_end = bip && !g->has_bias && !want_up ? class0_end : g->pk.n_pos;
+            const size_t scan_blocks = scan_end / 256;
             for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
                 const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
-                // all workgroups resident at once (32 KB of LDS each: 4 per CU), every one walks its share of the blocks
-                const size_t gx = std::min(nblocks, std::max<size_t>(1, (1024 + ng - 1) / ng));
-                HIP_TRY(rj_launch_measure(dim3(unsigned(gx), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj, g->pk.site,
-                                          g->n_colours == 2 ? uint32_t(g->class_base[1]) : 0u, counts_slot + 2 * 32 * g0));
+                const size_t gx = std::min(scan_blocks, std::max<size_t>(1, resident / ng));
+                HIP_TRY(rj_launch_measure(dim3(unsigned(std::max<size_t>(gx, 1)), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj,
+                                          g->pk.site, class0_end, scan_end, want_up, counts_slot + 2 * 32 * g0));
             }
             return ISINGMC_OK;
         }
@@ -2304,7 +2359,7 @@ static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalizati
             TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
             HIP_TRY(hipMemcpyAsync(s->d_samples[b] + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
             TRY(measure_enqueue(s, counts ? s->d_sample_counts[b] + k * CS * 2 : nullptr, counts ? nullptr : s->d_sample_e[b] + k * R,
-                                counts ? nullptr : s->d_sample_m));
+                                counts ? nullptr : s->d_sample_m, /*want_up=*/false));
         }
         HIP_TRY(hipEventRecord(s->sample_ready[b], s->stream));
         HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->sample_ready[b], 0));

@@ -465,9 +465,13 @@ public:
         graph_ = make_graph(E_, bias.empty() ? nullptr : &bias, default_device(), false);
         st_ = std::make_shared<StatesHandle>();
         st_->graph = graph_;
-        check(isingmc_states_create(graph_->g, 0, nullptr, nullptr, &st_->s));
+        // all experiments of the constructor at once (seed i = the i-th draw of the container's rng, as add_graph would
+        // draw them one by one): the library picks its path from the count -- from 16 experiments on a graph that is not a
+        // recognised lattice runs on the replica-packed kernels -- and later add_graph calls grow that container
         const size_t n = num_experiments.value_or(1);
-        for (size_t i = 0; i < n; i++) add_graph(std::nullopt, std::nullopt);
+        drawn_.resize(n);
+        check(isingmc_host_make_seeds(1, master_seed_, n, drawn_.data()));
+        check(isingmc_states_create(graph_->g, n, drawn_.data(), nullptr, &st_->s));
     }
 
     // classicising.rs:62-79: seed = self.rng.gen(); GraphState::new / new_with_state_and_rng

@@ -1,6 +1,8 @@
 // Translation unit of the replica-packed real-coupling kernels (see real_types.hpp for why it is apart from isingmc.hip).
 #include "real_kernels.hpp"
 
+#include <type_traits>
+
 namespace isingmc {
 
 hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
@@ -14,14 +16,34 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
     return hipGetLastError();
 }
 
-hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
-                             uint32_t class0_end, unsigned long long *out)
+template <typename F>
+static void rj_pick_measure(uint32_t slots, bool bip, bool up, F &&f)
 {
-    const auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(RJ_THREADS), 0, stream, state, G, site, class0_end, out); };
-    const bool bip = class0_end != 0;
-    if (G.slots == 4) { if (bip) launch(rj_measure_kernel<4, true>); else launch(rj_measure_kernel<4, false>); }
-    else { if (bip) launch(rj_measure_kernel<7, true>); else launch(rj_measure_kernel<7, false>); }
+    const auto with = [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        if (bip) { if (up) f(rj_measure_kernel<S, true, true>); else f(rj_measure_kernel<S, true, false>); }
+        else { if (up) f(rj_measure_kernel<S, false, true>); else f(rj_measure_kernel<S, false, false>); }
+    };
+    if (slots == 4) with(std::integral_constant<int, 4>{}); else with(std::integral_constant<int, 7>{});
+}
+
+hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
+                             uint32_t class0_end, uint32_t scan_end, bool count_up, unsigned long long *out)
+{
+    rj_pick_measure(G.slots, class0_end != 0, count_up, [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(RJ_THREADS), 0, stream, state, G, site, class0_end, scan_end, out);
+    });
     return hipGetLastError();
+}
+
+int rj_measure_blocks_per_cu(uint32_t slots, bool bipartite, bool count_up)
+{
+    int n = 0;
+    rj_pick_measure(slots, bipartite, count_up, [&](auto kernel) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, RJ_THREADS, 0) != hipSuccess) n = 0;
+    });
+    (void)hipGetLastError();
+    return n;
 }
 
 } // namespace isingmc

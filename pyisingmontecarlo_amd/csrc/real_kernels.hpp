@@ -170,38 +170,41 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restri
 
 // -2 x (energy in units of 2^k) and the up spins, per replica.  General graphs: sum over the real positions of
 // X + s hq = 2 s hq - s F (every bond is seen from both ends).  BIP (two colour classes: every bond joins class 0 to
-// class 1): the bonds are taken from the class-0 positions only (p < class0_end: 2 X = 2 s hq - 2 s F), the class-1
-// positions add just their bias term 2 s hq -- no gathers, no table there.  A thread walks positions blockIdx.x * 256 + tid,
-// + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
-template <int SLOTS, bool BIP>
+// class 1): the bonds are taken from the class-0 positions only (p < class0_end: 2 X = 2 s hq - 2 s F); the class-1
+// positions add just their bias term 2 s hq (as sites without bonds: no gathers) and are not visited at all when the graph
+// has no biases (scan_end = class0_end; with UP the scan covers every position).  A thread walks positions
+// blockIdx.x * 256 + tid, + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
+// UP: also count the up spins (get_magnetisations); the energy-only callers save 32 registers per thread (a wave more per SIMD)
+template <int SLOTS, bool BIP, bool UP>
 __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *__restrict__ state, const RjGraphDev G,
                                                                 const uint32_t *__restrict__ site, const uint32_t class0_end,
-                                                                unsigned long long *__restrict__ out)
+                                                                const uint32_t scan_end, unsigned long long *__restrict__ out)
 {
     __shared__ uint32_t s_x[32 * RJ_THREADS];
     const uint32_t tid = threadIdx.x, g = blockIdx.y;
     const uint32_t *st = state + size_t(g) * G.n_pos;
     long long acc[32];
-    uint32_t up[32];
+    uint32_t up[UP ? 32 : 1];
 #pragma unroll
-    for (int b = 0; b < 32; b++) { acc[b] = 0; up[b] = 0; }
-    for (uint32_t base = blockIdx.x * RJ_THREADS; base < G.n_pos; base += gridDim.x * RJ_THREADS) { // base: wave-uniform
+    for (int b = 0; b < 32; b++) acc[b] = 0;
+#pragma unroll
+    for (int b = 0; b < (UP ? 32 : 1); b++) up[b] = 0;
+    for (uint32_t base = blockIdx.x * RJ_THREADS; base < scan_end; base += gridDim.x * RJ_THREADS) { // base: wave-uniform
         const uint32_t p = base + tid;
         if (site[p] == RJ_PAD_SITE) continue;
-        if (BIP && base >= class0_end) { // class boundaries are multiples of 256: uniform per workgroup
-            const uint32_t own = st[p];
-            const long long h2 = 2ll * G.hq[p];
-#pragma unroll
-            for (int b = 0; b < 32; b++) {
-                const uint32_t bit = (own >> b) & 1u;
-                acc[b] += bit ? h2 : -h2;
-                up[b] += bit;
-            }
-            continue;
-        }
         uint32_t own, w[8];
         int32_t jq[SLOTS], hq;
-        rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
+        if (!BIP || base < class0_end) { // class boundaries are multiples of 256: uniform per workgroup
+            rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
+        } else { // class 1 of a two-class graph: only the bias term 2 s hq = 2 X of a site without bonds -- no gathers
+            own = st[p];
+            hq = G.hq[p];
+#pragma unroll
+            for (int e = 0; e < SLOTS; e++) jq[e] = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = 0u;
+            w[SLOTS == 4 ? 4 : 7] = own;
+        }
         rj_build_tables<SLOTS, BIP ? 1 : 2, false>(s_x, tid, jq, hq, 0u);
         rj_transpose(w);
 #pragma unroll
@@ -209,22 +212,44 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *
             const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
             const long long x = (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, idx));
             acc[b] += BIP ? 2 * x : x;
-            up[b] += (own >> b) & 1u;
+            if constexpr (UP) up[b] += (own >> b) & 1u;
         }
     }
+    // Reduce-scatter over the wave: in step k (lane distance 1, 2, 4, 8, 16) a lane keeps the half of its sums whose replica
+    // index has bit k equal to its own lane bit and hands the other half to its partner -- 16 + 8 + 4 + 2 + 1 exchanges instead
+    // of 32 full butterflies; lane l then holds replica l & 31, summed over the lanes that agree with it in bit 5, and one
+    // more exchange (distance 32) finishes.  Four waves meet in LDS: 32 atomics per workgroup, all to different addresses
+    // (one atomic per wave and replica took longer than the scan itself: 164 000 atomics on 128 addresses).
+    const uint32_t lane = tid & 63u;
 #pragma unroll
-    for (int b = 0; b < 32; b++) {
-        long long a = acc[b];
-        uint32_t u = up[b];
+    for (int k = 0; k < 5; k++) {
+        const bool hi = (lane >> k) & 1u;
+        const int half = 16 >> k; // sums that survive this step
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            a += __shfl_xor(a, off);
-            u += __shfl_xor(u, off);
+        for (int i = 0; i < half; i++) {
+            // before step k the surviving sums sit at acc[0 .. 2 half); entry j stands for a replica index whose bit k is j / half
+            const long long keep = hi ? acc[i + half] : acc[i], send = hi ? acc[i] : acc[i + half];
+            acc[i] = keep + __shfl_xor(send, 1 << k);
+            if constexpr (UP) {
+                const uint32_t ukeep = hi ? up[i + half] : up[i], usend = hi ? up[i] : up[i + half];
+                up[i] = ukeep + __shfl_xor(usend, 1 << k);
+            }
         }
-        if ((tid & 63u) == 0 && (a != 0 || u != 0)) {
-            atomicAdd(out + 2 * (size_t(32) * g + b), (unsigned long long)a);
-            atomicAdd(out + 2 * (size_t(32) * g + b) + 1, (unsigned long long)u);
-        }
+    }
+    long long a = acc[0] + __shfl_xor(acc[0], 32);
+    uint32_t u = UP ? up[0] + __shfl_xor(up[0], 32) : 0u;
+    // which replica does lane l hold?  Step k kept, of the two halves, the one matching lane bit k, and the halves were split by
+    // the TOP remaining index bit: step 0 decided index bit 4, step 1 bit 3, ... step 4 bit 0
+    const uint32_t b = ((lane & 1u) << 4) | ((lane & 2u) << 2) | (lane & 4u) | ((lane & 8u) >> 2) | ((lane & 16u) >> 4);
+    __shared__ long long red_a[4][32];
+    __shared__ uint32_t red_u[4][32];
+    if (lane < 32) { red_a[tid >> 6][b] = a; red_u[tid >> 6][b] = u; }
+    __syncthreads();
+    if (tid < 32) {
+        const long long ta = red_a[0][tid] + red_a[1][tid] + red_a[2][tid] + red_a[3][tid];
+        const uint32_t tu = red_u[0][tid] + red_u[1][tid] + red_u[2][tid] + red_u[3][tid];
+        if (ta != 0) atomicAdd(out + 2 * (size_t(32) * g + tid), (unsigned long long)ta);
+        if (UP && tu != 0) atomicAdd(out + 2 * (size_t(32) * g + tid) + 1, (unsigned long long)tu);
     }
 }
 

@@ -37,8 +37,13 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
 
 // out[2 slot] += -2 x (energy of replica slot in units of 2^k, bias terms included) as an int64 in two's complement,
 // out[2 slot + 1] += up spins; slot = 32 g + b.  class0_end: 0, or -- on a graph of exactly two colour classes -- the end
-// of class 0: the bonds are then counted from the class-0 positions alone.  Padding carries the PAD marker in `site`.
+// of class 0: the bonds are then counted from the class-0 positions alone.  scan_end: positions [0, scan_end) are visited
+// (n_pos; class0_end when the graph is two-coloured, has no biases and the up spins are not wanted).  Padding carries the
+// PAD marker in `site`.
+// count_up: also the up spins (32 more registers per thread); energy-only callers pass false and leave out[2 slot + 1] alone.
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
-                             uint32_t class0_end, unsigned long long *out);
+                             uint32_t class0_end, uint32_t scan_end, bool count_up, unsigned long long *out);
+// workgroups of that instantiation one CU holds (the launch is sized so that all of them are resident at once)
+int rj_measure_blocks_per_cu(uint32_t slots, bool bipartite, bool count_up);
 
 } // namespace isingmc

@@ -349,8 +349,10 @@ def test_packed_general_path_bit_exact(capi, oracle, exact, monkeypatch):
     st.set_state(33, other)                                                  # one replica of the second group
     got = st.states().astype(np.uint8)
     assert np.array_equal(got[33], other) and np.array_equal(got[32], s_ref[32]) and np.array_equal(got[34], s_ref[34])
-    with pytest.raises(ValueError, match="cannot grow"):
-        st.append(5)
+    # ClassicIsing.add_graph on a packed container (round 3): replica 35 joins the open group and takes over the chain bit 3 of
+    # group 1 has been running since the group was created
+    st.append(5)
+    assert st.count == 36 and np.array_equal(st.states().astype(np.uint8)[35], s_ref[35])
 
 
 def _circulant(n, offsets, J):

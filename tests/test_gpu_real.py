@@ -192,3 +192,40 @@ def test_tempering_on_the_real_coupling_path(capi, oracle, exact, monkeypatch):
     assert runs[0][3] == runs[1][3] > 0
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)
+
+
+def test_classic_ising_on_the_packed_paths_and_append(oracle, exact, monkeypatch):
+    """ClassicIsing (classicising.rs:27-110) with 16+ experiments on a graph that is not a recognised lattice: the constructor
+    creates them at once, so the replica-packed kernels serve them (bit-sliced path: uniform |J|; real-coupling path:
+    anything else), and add_graph grows the container -- into the open group, or opening a new one at a multiple of 32."""
+    import py_monte_carlo
+    W, H = 120, 120                                               # 14 400 sites, not 64-wide: general path, above the resident bound
+    N = W * H
+    ea, eb, ej_u = exact.square_lattice_edges(W, H, -1.0)
+    ej_g = np.random.default_rng(3).normal(size=len(ea))
+    edges = lambda ej: [((int(a), int(b)), float(j)) for a, b, j in zip(ea, eb, ej)]
+    for ej, run in ((ej_u, oracle.pk_run), (ej_g, oracle.rj_run)):
+        ci = py_monte_carlo.ClassicIsing(edges(ej), None, 31, 42)
+        seeds = list(oracle.make_seeds(42, 31))
+        ci.run_monte_carlo(0.6, 2)
+        _, ref = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 2, betas=[0.6] * 2)
+        assert np.array_equal(ci.get_states(), ref[:31].astype(bool))
+        # replica 31 joins the open group: it takes over the chain bit 31 has been running since t = 0
+        ci.add_graph()
+        seeds.append(int(oracle.make_seeds(42, 32)[-1]))
+        assert ci.get_num_graphs() == 32 and np.array_equal(ci.get_states()[31], ref[31].astype(bool))
+        # replica 32 opens a new group, keyed by its seed, started now (t = 2); replica 33 comes with an explicit state
+        ci.add_graph()
+        seeds.append(int(oracle.make_seeds(42, 33)[-1]))
+        up = [True] * N
+        ci.add_graph(up)
+        seeds.append(int(oracle.make_seeds(42, 34)[-1]))
+        ci.run_monte_carlo(0.6, 3)
+        e_all, s_all = ci.get_energies(), ci.get_states()
+        e0, ref0 = run(ea, eb, ej, N, np.array(seeds[:32], dtype=np.uint64), 3, betas=[0.6] * 3, states=ref, t0=2)
+        assert np.array_equal(s_all[:32], ref0[:32].astype(bool)) and np.array_equal(e_all[:32], e0)
+        # the second group on its own: random start, then replica 33 (bit 1) set to all up, three timesteps from t = 2
+        _, start = run(ea, eb, ej, N, np.array(seeds[32:], dtype=np.uint64), 0, betas=[])
+        start[1] = 1
+        e1, ref1 = run(ea, eb, ej, N, np.array(seeds[32:], dtype=np.uint64), 3, betas=[0.6] * 3, states=start, t0=2)
+        assert np.array_equal(s_all[32:], ref1[:2].astype(bool)) and np.array_equal(e_all[32:], e1)
