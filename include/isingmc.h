@@ -70,7 +70,7 @@ typedef struct {
     int32_t field_signs; /* LATTICE2D: 1 when the biases are +-field from site to site (sign planes), field = |h| then */
     int32_t packed_degree; /* GENERAL: d in 3..6 when the replica-packed path may use its one-degree kernel
                               (every site has d neighbours, every coupling the same size), else 0 */
-    int32_t real_slots;    /* GENERAL: 4 or 7 when the replica-packed REAL-COUPLING path applies (any f64 couplings,
+    int32_t real_slots;    /* GENERAL: 4, 7, 11 or 15 when the replica-packed REAL-COUPLING path applies (any f64 couplings,
                               lattice.rs:46-50, and any site biases, lattice.rs:104-131; degree <= real_slots), else 0 */
     int32_t real_quantum_log2; /* that path computes with couplings rounded to multiples of 2^real_quantum_log2
                               (2^-30 of the largest |h_i| + sum_e |J_e|); its energies are those of the rounded couplings */
@@ -119,9 +119,9 @@ int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, co
 /* Host halves of the replica-packed REAL-COUPLING path -- what the device kernels are fed with, exposed
  * so that they can be checked without a GPU.  That path serves edge lists with couplings of several sizes
  * (lattice.rs:46-50 takes any f64) and arbitrary site biases (set_individual_bias / set_global_bias, lattice.rs:104-131)
- * on graphs of degree <= 7: couplings and biases become integers in units of 2^k, k = ilogb(Fmax) + 1 - 30,
+ * on graphs of degree <= 15: couplings and biases become integers in units of 2^k, k = ilogb(Fmax) + 1 - 30,
  * Fmax = max_i (|h_i| + sum_e |J_e|).  jq_out: one value per input edge (0 for self-loops), hq_out: one per site;
- * *eligible_out: degree <= 7 and Fmax <= 64 x the median nonzero |coupling or bias| (else the f64 CSR path is used). */
+ * *eligible_out: degree <= 15 and Fmax <= 64 x the median nonzero |coupling or bias| (else the f64 CSR path is used). */
 int isingmc_host_rj_quantise(const uint64_t *edge_a, const uint64_t *edge_b, const double *edge_j, size_t n_edges,
                              size_t nvars, const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out,
                              int *eligible_out);

@@ -861,7 +861,7 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
 /* ==========================================================================================
  * E. replica-packed REAL-COUPLING engine: any real J and any site biases
  * (lattice.rs:46-50 edge list, :104-131 set_individual_bias / set_global_bias, :186-189), graphs of
- * degree <= 7.  Same colouring, positions, replica groups, group keys and random start as engine D.
+ * degree <= 15.  Same colouring, positions, replica groups, group keys and random start as engine D.
  * The acceptance test runs in the LOG domain on integers, so that nothing per attempt needs exp():
  *
  *   quantisation (once per graph)   k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
@@ -881,7 +881,7 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
  * transposition and carry tricks are checked against this independently.
  * ======================================================================================== */
 #define DOM_RJ_SWEEP 0x524A5357u /* "RJSW" */
-#define RJ_MAX_DEG 7
+#define RJ_MAX_DEG 15
 #define RJ_LOG_INTERVALS 2048
 
 /* LT[i] ~ log2(1 + x_i) 2^24, x_i = i / 2048, i = 0 .. 2048, centred for the interpolation that uses it: the chord of
@@ -932,7 +932,7 @@ void orc_rj_quantise(size_t n_edges, const uint64_t *ea, const uint64_t *eb, con
         hq_out[i] = biases ? (int32_t)nearbyint(ldexp(biases[i], -k)) : 0;
 }
 
-/* eligibility for this path: degree <= 7, Fmax > 0 and Fmax <= 64 x the (lower) median nonzero |coupling or bias|: the
+/* eligibility for this path: degree <= 15, Fmax > 0 and Fmax <= 64 x the (lower) median nonzero |coupling or bias|: the
  * absolute rounding error 2^(k-1) of a coupling is then below 2^-25 of that median */
 static int cmp_double(const void *a, const void *b)
 {

@@ -297,7 +297,7 @@ RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases)
         std::nth_element(mags.begin(), mags.begin() + (mags.size() - 1) / 2, mags.end());
         median = mags[(mags.size() - 1) / 2];
     }
-    Q.eligible = Q.max_degree <= 7 && fmax > 0.0 && fmax <= 64.0 * median;
+    Q.eligible = Q.max_degree <= 15 && fmax > 0.0 && fmax <= 64.0 * median;
     return Q;
 }
 

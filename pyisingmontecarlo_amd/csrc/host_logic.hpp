@@ -66,7 +66,7 @@ uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const doub
 
 // ---- replica-packed real-coupling path: host halves of the spec ---------------------------
 // Couplings and biases as integers in units of 2^k: k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
-// jq in ADJACENCY order (A.w's), hq per site.  eligible: degree <= 7, Fmax > 0 and Fmax <= 64 x the median nonzero
+// jq in ADJACENCY order (A.w's), hq per site.  eligible: degree <= 15, Fmax > 0 and Fmax <= 64 x the median nonzero
 // |coupling or bias| (the absolute rounding error 2^(k-1) of a coupling then stays below 2^-25 of that median; one
 // enormous bias or coupling would otherwise set a quantum that wipes out the ordinary ones).
 struct RjQuant {

@@ -90,7 +90,7 @@ struct isingmc_graph {
     PkUniHeaders pk_uni{};
     std::vector<uint32_t> pk_class_full; // per colour class: end of its last 256-block without padding
     uint64_t n_directed = 0;
-    // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 7
+    // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 15
     bool rj_ok = false;
     RjGraphDev rj{};
     int rj_k = 0;                         // couplings are integers in units of 2^rj_k
@@ -745,11 +745,11 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
         g->class_real_end[c] = uint32_t(C.class_base[c]) + real;
     }
     // real-coupling packed path: whatever the bit-sliced packed path cannot take (couplings of several sizes, site
-    // biases), degree <= 7, quantisation faithful (rj_quantise)
+    // biases), degree <= 15, quantisation faithful (rj_quantise)
     if (!g->packed_ok && n_pos < 0x80000000u) {
         const RjQuant Q = rj_quantise(A, nvars, biases);
         if (Q.eligible) {
-            const uint32_t slots = Q.max_degree <= 4 ? 4u : 7u;
+            const uint32_t slots = Q.max_degree <= 4 ? 4u : Q.max_degree <= 7 ? 7u : Q.max_degree <= 11 ? 11u : 15u;
             std::vector<uint32_t> enbr(size_t(slots) * n_pos);
             std::vector<int32_t> ejq(size_t(slots) * n_pos, 0), ehq(n_pos, 0);
             for (uint32_t i = 0; i < slots; i++)
@@ -1098,18 +1098,29 @@ static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
     return g->state_words * sizeof(uint32_t) <= GEN_RESIDENT_MAX_BYTES && g->nvars <= (n_replicas < 16 ? 8000u : 12000u);
 }
 
+// Packed or per-replica?  The packed kernels launch once per colour class and timestep; the LDS-resident CSR kernel runs a whole
+// call in one launch with one workgroup per replica, which wins on small graphs.  Measured crossover (Gaussian glasses, 16-1024
+// replicas, tools/real_small.py, profiles/r03_real_small.txt): the packed real-coupling path is ahead from 8 000 sites on at any
+// replica count >= 16 (1.7-8x), at 4 096 sites from 256 replicas (1.5-5x), at 1 728 sites from 1 024 (2.6x), never at 1 024 sites.
+static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas)
+{
+    if (n_replicas < 16) return false;
+    if (!gen_resident_fits(g, n_replicas)) return true; // the per-replica alternative would be the slow per-class CSR launches
+    return g->nvars >= 8000 || (g->nvars >= 1500 && uint64_t(g->nvars) * n_replicas >= (uint64_t(1) << 20));
+}
+
 // 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
 static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL")) {
         if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
-        return n_replicas >= 16 && !gen_resident_fits(g, n_replicas) ? 2 : 0;
+        return packed_worth_it(g, n_replicas) ? 2 : 0;
     }
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
     if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0 ? 1 : 0;
-    return n_replicas >= 16 && !gen_resident_fits(g, n_replicas) ? 1 : 0;
+    return packed_worth_it(g, n_replicas) ? 1 : 0;
 }
 
 // threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)
@@ -1254,7 +1265,8 @@ static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t 
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = g->class_real_end[c];
         if (e == b) continue;
-        const size_t nblocks = (size_t(e - b) + 255) / 256;
+        const size_t threads = rj_threads(g->rj.slots);
+        const size_t nblocks = (size_t(e - b) + threads - 1) / threads;
         for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
             const size_t gx0 = std::min(nblocks, std::max<size_t>(1, (size_t(target_wgs) + ng - 1) / ng));
@@ -2169,14 +2181,14 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
             (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
             // all workgroups resident at once (the runtime's occupancy figure for this instantiation), every one walks its
             // share of the blocks; a grid one round and a bit long would run its tail at a fraction of the chip
-            static int per_cu[2][2][2] = {};
-            int &pc = per_cu[g->rj.slots == 7][bip][want_up];
+            static int per_cu[4][2][2] = {};
+            int &pc = per_cu[g->rj.slots == 4 ? 0 : g->rj.slots == 7 ? 1 : g->rj.slots == 11 ? 2 : 3][bip][want_up];
             if (pc == 0) pc = std::max(1, rj_measure_blocks_per_cu(g->rj.slots, bip, want_up));
             const size_t resident = size_t(pc) * size_t(std::max(dev_cus, 1));
             // two colour classes: the bonds from class 0 alone; class 1 is visited only for its bias terms or the up spins
             const uint32_t class0_end = bip ? uint32_t(g->class_base[1]) : 0u;
             const uint32_t scan_end = bip && !g->has_bias && !want_up ? class0_end : g->pk.n_pos;
-            const size_t scan_blocks = scan_end / 256;
+            const size_t scan_blocks = scan_end / rj_threads(g->rj.slots);
             for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
                 const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
                 const size_t gx = std::min(scan_blocks, std::max<size_t>(1, resident / ng));

@@ -248,7 +248,7 @@ public:
         d["open_x"] = bool(info.open_x);
         d["open_y"] = bool(info.open_y);
         d["packed_degree"] = info.packed_degree;
-        d["real_slots"] = info.real_slots; // 4 / 7: the real-coupling packed path applies (from 16 experiments on)
+        d["real_slots"] = info.real_slots; // 4 / 7 / 11 / 15: the real-coupling packed path applies (from 16 experiments on)
         d["real_quantum_log2"] = info.real_quantum_log2;
         return d;
     }

@@ -5,33 +5,50 @@
 
 namespace isingmc {
 
+template <typename F>
+static void rj_with_slots(uint32_t slots, F &&f)
+{
+    if (slots == 4) f(std::integral_constant<int, 4>{});
+    else if (slots == 7) f(std::integral_constant<int, 7>{});
+    else if (slots == 11) f(std::integral_constant<int, 11>{});
+    else f(std::integral_constant<int, 15>{});
+}
+
+uint32_t rj_threads(uint32_t slots)
+{
+    uint32_t n = 256;
+    rj_with_slots(slots, [&](auto s_c) { n = uint32_t(RjShape<decltype(s_c)::value>::THREADS); });
+    return n;
+}
+
 hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
                            uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride)
 {
-    const auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(RJ_THREADS), 0, stream, state, G, class_begin, real_end, t, group_keys, betas);
-    };
-    if (G.slots == 4) { if (beta_stride == 0) launch(rj_sweep_kernel<4, true>); else launch(rj_sweep_kernel<4, false>); }
-    else { if (beta_stride == 0) launch(rj_sweep_kernel<7, true>); else launch(rj_sweep_kernel<7, false>); }
+    rj_with_slots(G.slots, [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        const auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(RjShape<S>::THREADS), 0, stream, state, G, class_begin, real_end, t, group_keys, betas);
+        };
+        if (beta_stride == 0) launch(rj_sweep_kernel<S, true>); else launch(rj_sweep_kernel<S, false>);
+    });
     return hipGetLastError();
 }
 
 template <typename F>
 static void rj_pick_measure(uint32_t slots, bool bip, bool up, F &&f)
 {
-    const auto with = [&](auto s_c) {
+    rj_with_slots(slots, [&](auto s_c) {
         constexpr int S = decltype(s_c)::value;
-        if (bip) { if (up) f(rj_measure_kernel<S, true, true>); else f(rj_measure_kernel<S, true, false>); }
-        else { if (up) f(rj_measure_kernel<S, false, true>); else f(rj_measure_kernel<S, false, false>); }
-    };
-    if (slots == 4) with(std::integral_constant<int, 4>{}); else with(std::integral_constant<int, 7>{});
+        if (bip) { if (up) f(rj_measure_kernel<S, true, true>, RjShape<S>::THREADS); else f(rj_measure_kernel<S, true, false>, RjShape<S>::THREADS); }
+        else { if (up) f(rj_measure_kernel<S, false, true>, RjShape<S>::THREADS); else f(rj_measure_kernel<S, false, false>, RjShape<S>::THREADS); }
+    });
 }
 
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
                              uint32_t class0_end, uint32_t scan_end, bool count_up, unsigned long long *out)
 {
-    rj_pick_measure(G.slots, class0_end != 0, count_up, [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(RJ_THREADS), 0, stream, state, G, site, class0_end, scan_end, out);
+    rj_pick_measure(G.slots, class0_end != 0, count_up, [&](auto kernel, int threads) {
+        hipLaunchKernelGGL(kernel, grid, dim3(threads), 0, stream, state, G, site, class0_end, scan_end, out);
     });
     return hipGetLastError();
 }
@@ -39,8 +56,8 @@ hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *stat
 int rj_measure_blocks_per_cu(uint32_t slots, bool bipartite, bool count_up)
 {
     int n = 0;
-    rj_pick_measure(slots, bipartite, count_up, [&](auto kernel) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, RJ_THREADS, 0) != hipSuccess) n = 0;
+    rj_pick_measure(slots, bipartite, count_up, [&](auto kernel, int threads) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess) n = 0;
     });
     (void)hipGetLastError();
     return n;

@@ -19,7 +19,6 @@
 
 namespace isingmc {
 
-constexpr int RJ_THREADS = 256;
 constexpr uint32_t RJ_PAD_SITE = 0xFFFFFFFFu; // == PAD_SITE (general_kernels.hpp)
 
 // One step of the transposition: swap the high sub-blocks (bits m << s) of x with the low sub-blocks (bits m) of y.
@@ -52,60 +51,82 @@ __device__ __forceinline__ uint32_t rj_lambda(const uint32_t u, const uint2 *s_l
     return (159u << 24) - ((bits >> 23) << 24) - val;
 }
 
-// The per-thread column of X values.  SLOTS == 4: one table of 32 entries indexed by (a_0..a_3, own);
-// SLOTS == 7: two tables of 16, A indexed by (a_0..a_3) and B by (a_4, a_5, a_6, own), X = A + B.
-// HSCALE: 1 for the sweep (X), 2 for the measurement (X + s hq = 2 s hq - SJ + 2 sum_{a} Jq).
-// FOLD: store max(X >> shift, 0) (one beta for all replicas, SLOTS == 4) instead of X.
+// Index of a replica at a position: bit e < SLOTS = a_e (bond e antiparallel), bit SLOTS = the own spin (bit 4 when SLOTS == 4).
+// SLOTS == 4: ONE table of 32 entries indexed by those 5 bits.  SLOTS == 7 / 11 / 15: the 8 / 12 / 16 index bits are cut into
+// 2 / 3 / 4 nibbles with a 16-entry table each, X = the sum of the nibbles' entries (the constant - sum_e Jq_e and the own
+// spin's +- hq live in the nibble that holds the own bit).
+template <int SLOTS>
+struct RjShape {
+    static_assert(SLOTS == 4 || SLOTS == 7 || SLOTS == 11 || SLOTS == 15, "slots");
+    static constexpr int NIB = SLOTS == 4 ? 0 : (SLOTS + 4) / 4;      // nibble tables (0: the single 32-entry table)
+    static constexpr int ENTRIES = SLOTS == 4 ? 32 : 16 * NIB;        // LDS words per thread
+    static constexpr int WORDS = SLOTS <= 7 ? 8 : 16;                 // index words before transposition
+    static constexpr int OWN_BIT = SLOTS == 4 ? 4 : SLOTS;
+    static constexpr int THREADS = SLOTS <= 7 ? 256 : 128;            // workgroup size (48 / 64 table words per thread: half the threads)
+};
+
+// The per-thread column of X values.  HSCALE: 1 for the sweep (X), 2 for the measurement of a general graph
+// (X + s hq = 2 s hq - SJ + 2 sum_{a} Jq).  FOLD: store max(X >> shift, 0) (one beta for all replicas, SLOTS == 4) instead of X.
 template <int SLOTS, int HSCALE, bool FOLD>
 __device__ __forceinline__ void rj_build_tables(uint32_t *s_x, const uint32_t tid, const int32_t (&jq)[SLOTS], const int32_t hq,
                                                 const uint32_t shift)
 {
+    using SH = RjShape<SLOTS>;
     int32_t sj = 0;
 #pragma unroll
     for (int e = 0; e < SLOTS; e++) sj += jq[e];
-    int32_t sub[16]; // 2 x subset sums of the first four couplings
-    sub[0] = 0;
-#pragma unroll
-    for (int n = 1; n < 16; n++) sub[n] = sub[n & (n - 1)] + 2 * jq[__builtin_ctz(n) < SLOTS ? __builtin_ctz(n) : 0];
     if constexpr (SLOTS == 4) {
+        int32_t sub[16]; // 2 x subset sums of the four couplings
+        sub[0] = 0;
+#pragma unroll
+        for (int n = 1; n < 16; n++) sub[n] = sub[n & (n - 1)] + 2 * jq[__builtin_ctz(n)];
 #pragma unroll
         for (int n = 0; n < 16; n++) {
             const int32_t x0 = sub[n] - sj - HSCALE * hq, x1 = sub[n] - sj + HSCALE * hq; // own spin down / up
             if constexpr (FOLD) {
-                s_x[n * RJ_THREADS + tid] = uint32_t(max(x0 >> shift, 0));
-                s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(max(x1 >> shift, 0));
+                s_x[n * RjShape<SLOTS>::THREADS + tid] = uint32_t(max(x0 >> shift, 0));
+                s_x[(16 + n) * RjShape<SLOTS>::THREADS + tid] = uint32_t(max(x1 >> shift, 0));
             } else {
-                s_x[n * RJ_THREADS + tid] = uint32_t(x0);
-                s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(x1);
+                s_x[n * RjShape<SLOTS>::THREADS + tid] = uint32_t(x0);
+                s_x[(16 + n) * RjShape<SLOTS>::THREADS + tid] = uint32_t(x1);
             }
         }
     } else {
 #pragma unroll
-        for (int n = 0; n < 16; n++) s_x[n * RJ_THREADS + tid] = uint32_t(sub[n]);
-        int32_t subb[8];
-        subb[0] = 0;
+        for (int nb = 0; nb < SH::NIB; nb++) {
+            int32_t sub[16];
+            sub[0] = nb == SH::OWN_BIT / 4 ? -sj - HSCALE * hq : 0; // the own bit's nibble carries the constants (own spin down)
 #pragma unroll
-        for (int n = 1; n < 8; n++) subb[n] = subb[n & (n - 1)] + 2 * jq[4 + __builtin_ctz(n)];
+            for (int n = 1; n < 16; n++) {
+                const int bit = 4 * nb + __builtin_ctz(n); // the index bit this pattern adds
+                const int32_t add = bit < SLOTS ? 2 * jq[bit < SLOTS ? bit : 0] : bit == SH::OWN_BIT ? 2 * HSCALE * hq : 0;
+                sub[n] = sub[n & (n - 1)] + add;
+            }
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
-            s_x[(16 + n) * RJ_THREADS + tid] = uint32_t(subb[n] - sj - HSCALE * hq);
-            s_x[(24 + n) * RJ_THREADS + tid] = uint32_t(subb[n] - sj + HSCALE * hq);
+            for (int n = 0; n < 16; n++) s_x[(16 * nb + n) * RjShape<SLOTS>::THREADS + tid] = uint32_t(sub[n]);
         }
     }
 }
 
-// X (or the folded threshold operand) of the replica whose index byte is `idx`
+// X (or the folded threshold operand) of the replica whose index is `idx` (16 bits: the low byte from the first transposition,
+// the high byte from the second)
 template <int SLOTS>
 __device__ __forceinline__ uint32_t rj_lookup(const uint32_t *s_x, const uint32_t tid, const uint32_t idx)
 {
-    if constexpr (SLOTS == 4) return s_x[idx * RJ_THREADS + tid];
-    else return s_x[(idx & 15u) * RJ_THREADS + tid] + s_x[(16u + (idx >> 4)) * RJ_THREADS + tid];
+    using SH = RjShape<SLOTS>;
+    if constexpr (SLOTS == 4) return s_x[idx * RjShape<SLOTS>::THREADS + tid];
+    else {
+        uint32_t x = s_x[(idx & 15u) * RjShape<SLOTS>::THREADS + tid];
+#pragma unroll
+        for (int nb = 1; nb < SH::NIB; nb++) x += s_x[(16u * nb + ((idx >> (4 * nb)) & 15u)) * RjShape<SLOTS>::THREADS + tid];
+        return x;
+    }
 }
 
-// gather: own word, neighbour words, couplings, bias of position p; w[] = the 8 index words before transposition
+// gather: own word, neighbour words, couplings, bias of position p; w[] = the index words before transposition
 template <int SLOTS>
 __device__ __forceinline__ void rj_gather(const uint32_t *__restrict__ st, const RjGraphDev &G, const uint32_t p, uint32_t &own,
-                                          int32_t (&jq)[SLOTS], int32_t &hq, uint32_t (&w)[8])
+                                          int32_t (&jq)[SLOTS], int32_t &hq, uint32_t (&w)[RjShape<SLOTS>::WORDS])
 {
     uint32_t q[SLOTS];
     own = st[p];
@@ -115,23 +136,65 @@ __device__ __forceinline__ void rj_gather(const uint32_t *__restrict__ st, const
     for (int e = 0; e < SLOTS; e++) jq[e] = G.jq[size_t(e) * G.n_pos + p];
     hq = G.hq[p];
 #pragma unroll
-    for (int e = 0; e < 8; e++) w[e] = 0u;
+    for (int e = 0; e < RjShape<SLOTS>::WORDS; e++) w[e] = 0u;
 #pragma unroll
     for (int e = 0; e < SLOTS; e++) w[e] = own ^ st[q[e]];
-    w[SLOTS == 4 ? 4 : 7] = own;
+    w[RjShape<SLOTS>::OWN_BIT] = own;
+}
+
+// a site without bonds (class 1 of a two-class graph in the measurement): only the own word and the bias
+template <int SLOTS>
+__device__ __forceinline__ void rj_gather_bias_only(const uint32_t *__restrict__ st, const RjGraphDev &G, const uint32_t p, uint32_t &own,
+                                                    int32_t (&jq)[SLOTS], int32_t &hq, uint32_t (&w)[RjShape<SLOTS>::WORDS])
+{
+    own = st[p];
+    hq = G.hq[p];
+#pragma unroll
+    for (int e = 0; e < SLOTS; e++) jq[e] = 0;
+#pragma unroll
+    for (int e = 0; e < RjShape<SLOTS>::WORDS; e++) w[e] = 0u;
+    w[RjShape<SLOTS>::OWN_BIT] = own;
+}
+
+// index words -> index bytes: w[b & 7] byte (b >> 3) = bits 0-7 of replica b's index, w[8 + (b & 7)] the same byte of bits 8-15
+template <int SLOTS>
+__device__ __forceinline__ void rj_transpose_all(uint32_t (&w)[RjShape<SLOTS>::WORDS])
+{
+    uint32_t lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) lo[e] = w[e];
+    rj_transpose(lo);
+#pragma unroll
+    for (int e = 0; e < 8; e++) w[e] = lo[e];
+    if constexpr (RjShape<SLOTS>::WORDS == 16) {
+        uint32_t hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) hi[e] = w[8 + e];
+        rj_transpose(hi);
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[8 + e] = hi[e];
+    }
+}
+
+template <int SLOTS>
+__device__ __forceinline__ uint32_t rj_index(const uint32_t (&w)[RjShape<SLOTS>::WORDS], const int b)
+{
+    uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
+    if constexpr (RjShape<SLOTS>::WORDS == 16) idx |= ((w[8 + (b & 7)] >> (8 * (b >> 3))) & 0xFFu) << 8;
+    return idx;
 }
 
 // one colour class of one timestep; blockIdx.y = replica group; a workgroup walks 256-position blocks of the class
 template <int SLOTS, bool UB>
-__global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
+__global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
                                                               const uint32_t real_end, const uint64_t t,
                                                               const uint2 *__restrict__ group_keys, const RjBeta *__restrict__ betas)
 {
     __shared__ uint2 s_log[RJ_LOG_INTERVALS];
-    __shared__ uint32_t s_x[32 * RJ_THREADS];
+    __shared__ uint32_t s_x[RjShape<SLOTS>::ENTRIES * RjShape<SLOTS>::THREADS];
     const uint32_t tid = threadIdx.x, g = blockIdx.y;
 #pragma unroll
-    for (int i = 0; i < RJ_LOG_INTERVALS / RJ_THREADS; i++) s_log[tid + RJ_THREADS * i] = G.logtab[tid + RJ_THREADS * i];
+    for (int i = 0; i < RJ_LOG_INTERVALS / RjShape<SLOTS>::THREADS; i++) s_log[tid + RjShape<SLOTS>::THREADS * i] = G.logtab[tid + RjShape<SLOTS>::THREADS * i];
     __syncthreads();
     uint32_t *st = state + size_t(g) * G.n_pos;
     const uint2 key = group_keys[g];
@@ -140,14 +203,14 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restri
     constexpr bool FOLD = UB && SLOTS == 4;
     const uint32_t shift0 = gb[0].shift, mant0 = gb[0].mant;
 
-    for (uint32_t base = class_begin + blockIdx.x * RJ_THREADS; base < real_end; base += gridDim.x * RJ_THREADS) {
+    for (uint32_t base = class_begin + blockIdx.x * RjShape<SLOTS>::THREADS; base < real_end; base += gridDim.x * RjShape<SLOTS>::THREADS) {
         const uint32_t p = base + tid;
         if (p >= real_end) continue; // (no barrier below: a thread reads only its own column of s_x)
-        uint32_t own, w[8];
+        uint32_t own, w[RjShape<SLOTS>::WORDS];
         int32_t jq[SLOTS], hq;
         rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
         rj_build_tables<SLOTS, 1, FOLD>(s_x, tid, jq, hq, shift0);
-        rj_transpose(w);
+        rj_transpose_all<SLOTS>(w);
         uint32_t flips = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) { // Philox call j serves replica bits 4j .. 4j+3
@@ -156,8 +219,7 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restri
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int b = 4 * j + i;
-                const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
-                const uint32_t xv = rj_lookup<SLOTS>(s_x, tid, idx);
+                const uint32_t xv = rj_lookup<SLOTS>(s_x, tid, rj_index<SLOTS>(w, b));
                 const uint32_t shift = UB ? shift0 : gb[b].shift, mant = UB ? mant0 : gb[b].mant;
                 const uint32_t xpos = FOLD ? xv : uint32_t(max(int32_t(xv) >> shift, 0));
                 const uint32_t y = __umulhi(rj_lambda(u4[i], s_log), mant);
@@ -176,11 +238,11 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_sweep_kernel(uint32_t *__restri
 // blockIdx.x * 256 + tid, + gridDim.x * 256, ... with 32 int64 accumulators; one wave reduction per replica at the end.
 // UP: also count the up spins (get_magnetisations); the energy-only callers save 32 registers per thread (a wave more per SIMD)
 template <int SLOTS, bool BIP, bool UP>
-__global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *__restrict__ state, const RjGraphDev G,
+__global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_measure_kernel(const uint32_t *__restrict__ state, const RjGraphDev G,
                                                                 const uint32_t *__restrict__ site, const uint32_t class0_end,
                                                                 const uint32_t scan_end, unsigned long long *__restrict__ out)
 {
-    __shared__ uint32_t s_x[32 * RJ_THREADS];
+    __shared__ uint32_t s_x[RjShape<SLOTS>::ENTRIES * RjShape<SLOTS>::THREADS];
     const uint32_t tid = threadIdx.x, g = blockIdx.y;
     const uint32_t *st = state + size_t(g) * G.n_pos;
     long long acc[32];
@@ -189,28 +251,20 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *
     for (int b = 0; b < 32; b++) acc[b] = 0;
 #pragma unroll
     for (int b = 0; b < (UP ? 32 : 1); b++) up[b] = 0;
-    for (uint32_t base = blockIdx.x * RJ_THREADS; base < scan_end; base += gridDim.x * RJ_THREADS) { // base: wave-uniform
+    for (uint32_t base = blockIdx.x * RjShape<SLOTS>::THREADS; base < scan_end; base += gridDim.x * RjShape<SLOTS>::THREADS) { // base: wave-uniform
         const uint32_t p = base + tid;
         if (site[p] == RJ_PAD_SITE) continue;
-        uint32_t own, w[8];
+        uint32_t own, w[RjShape<SLOTS>::WORDS];
         int32_t jq[SLOTS], hq;
-        if (!BIP || base < class0_end) { // class boundaries are multiples of 256: uniform per workgroup
-            rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
-        } else { // class 1 of a two-class graph: only the bias term 2 s hq = 2 X of a site without bonds -- no gathers
-            own = st[p];
-            hq = G.hq[p];
-#pragma unroll
-            for (int e = 0; e < SLOTS; e++) jq[e] = 0;
-#pragma unroll
-            for (int e = 0; e < 8; e++) w[e] = 0u;
-            w[SLOTS == 4 ? 4 : 7] = own;
-        }
+        // class boundaries are multiples of 256: uniform per workgroup.  Class 1 of a two-class graph: only the bias term
+        // 2 s hq = 2 X of a site without bonds -- no gathers
+        if (!BIP || base < class0_end) rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
+        else rj_gather_bias_only<SLOTS>(st, G, p, own, jq, hq, w);
         rj_build_tables<SLOTS, BIP ? 1 : 2, false>(s_x, tid, jq, hq, 0u);
-        rj_transpose(w);
+        rj_transpose_all<SLOTS>(w);
 #pragma unroll
         for (int b = 0; b < 32; b++) {
-            const uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
-            const long long x = (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, idx));
+            const long long x = (long long)int32_t(rj_lookup<SLOTS>(s_x, tid, rj_index<SLOTS>(w, b)));
             acc[b] += BIP ? 2 * x : x;
             if constexpr (UP) up[b] += (own >> b) & 1u;
         }
@@ -241,13 +295,16 @@ __global__ __launch_bounds__(RJ_THREADS) void rj_measure_kernel(const uint32_t *
     // which replica does lane l hold?  Step k kept, of the two halves, the one matching lane bit k, and the halves were split by
     // the TOP remaining index bit: step 0 decided index bit 4, step 1 bit 3, ... step 4 bit 0
     const uint32_t b = ((lane & 1u) << 4) | ((lane & 2u) << 2) | (lane & 4u) | ((lane & 8u) >> 2) | ((lane & 16u) >> 4);
-    __shared__ long long red_a[4][32];
-    __shared__ uint32_t red_u[4][32];
+    constexpr int NWAVES = RjShape<SLOTS>::THREADS / 64;
+    __shared__ long long red_a[NWAVES][32];
+    __shared__ uint32_t red_u[NWAVES][32];
     if (lane < 32) { red_a[tid >> 6][b] = a; red_u[tid >> 6][b] = u; }
     __syncthreads();
     if (tid < 32) {
-        const long long ta = red_a[0][tid] + red_a[1][tid] + red_a[2][tid] + red_a[3][tid];
-        const uint32_t tu = red_u[0][tid] + red_u[1][tid] + red_u[2][tid] + red_u[3][tid];
+        long long ta = 0;
+        uint32_t tu = 0;
+#pragma unroll
+        for (int wv = 0; wv < NWAVES; wv++) { ta += red_a[wv][tid]; tu += red_u[wv][tid]; }
         if (ta != 0) atomicAdd(out + 2 * (size_t(32) * g + tid), (unsigned long long)ta);
         if (UP && tu != 0) atomicAdd(out + 2 * (size_t(32) * g + tid) + 1, (unsigned long long)tu);
     }

@@ -1,6 +1,6 @@
 // Shared declarations of the replica-packed REAL-COUPLING path (real_kernels.hpp): any f64 couplings and
 // any site biases -- the edge list of lattice.rs:46-50 with set_individual_bias / set_global_bias (lattice.rs:104-131)
-// materialised as lattice.rs:186-189 does -- on graphs of degree <= 7.  Own translation unit (real_kernels.hip), like the
+// materialised as lattice.rs:186-189 does -- on graphs of degree <= 15.  Own translation unit (real_kernels.hip), like the
 // strip and multi-class kernels, so that the streaming lattice kernels keep their register allocation.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -9,7 +9,7 @@
 
 namespace isingmc {
 
-constexpr int RJ_MAX_DEG = 7;
+constexpr int RJ_MAX_DEG = 15;
 constexpr uint32_t DOM_RJ_SWEEP = 0x524A5357u; // "RJSW"
 constexpr int RJ_LOG_INTERVALS = 2048;         // intervals of the log2(1 + m) table (Q24 values, linear interpolation)
 
@@ -21,7 +21,7 @@ struct RjGraphDev {
     const int32_t *hq;   // [n_pos] quantised bias (0 on padding)
     const uint2 *logtab; // [RJ_LOG_INTERVALS] {LT[i], LT[i+1] - LT[i]}
     uint32_t n_pos;      // multiple of 256
-    uint32_t slots;      // 4 (every site has degree <= 4) or 7
+    uint32_t slots;      // 4, 7, 11 or 15: the smallest of them that holds the largest degree
 };
 
 // acceptance scale of one inverse temperature: accept iff max(X >> shift, 0) <= (Lambda_q(u) * mant) >> 32
@@ -43,6 +43,8 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
 // count_up: also the up spins (32 more registers per thread); energy-only callers pass false and leave out[2 slot + 1] alone.
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
                              uint32_t class0_end, uint32_t scan_end, bool count_up, unsigned long long *out);
+// threads per workgroup of the kernels for `slots` (256, or 128 for 11 / 15 slots: their per-thread tables are 48 / 64 words)
+uint32_t rj_threads(uint32_t slots);
 // workgroups of that instantiation one CU holds (the launch is sized so that all of them are resident at once)
 int rj_measure_blocks_per_cu(uint32_t slots, bool bipartite, bool count_up);
 

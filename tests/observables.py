@@ -105,11 +105,11 @@ def main():
     gh = rng.choice([-0.5, 0.0, 0.5], size=16)
     enum_case("16-spin +-J graph with fields", ga, gb, gj, 16, 0.5, gh, 512, 200, 4000, 108)
     deg = np.bincount(np.concatenate([ga, gb]).astype(np.int64), minlength=16).max()
-    if deg <= 7:
+    if deg <= 15:
         enum_case("16-spin +-J graph with fields", ga, gb, gj, 16, 0.5, gh, 512, 200, 4000, 109, env={"ISINGMC_FORCE_REAL": "1"})
     gj2 = rng.normal(size=len(pairs))
     gh2 = rng.normal(size=16) * 0.4
-    if deg <= 7:
+    if deg <= 15:
         enum_case("16-spin Gaussian graph with fields", ga, gb, gj2, 16, 0.5, gh2, 512, 200, 4000, 110, env={"ISINGMC_FORCE_REAL": "1"})
     zs = np.array([r["z"] for r in rows])
     summary = {"rows": len(rows), "max_abs_z": float(np.abs(zs).max()), "rms_z": float(np.sqrt((zs ** 2).mean())),

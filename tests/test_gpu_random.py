@@ -78,13 +78,13 @@ def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_repl
 
 @st.composite
 def random_real_graph(draw):
-    """any couplings / biases, degree <= 7: what the real-coupling packed path takes (duplicate bonds and self-loops included)"""
+    """any couplings / biases, degree <= 15: what the real-coupling packed path takes (duplicate bonds and self-loops included)"""
     n = draw(st.integers(2, 90))
     m = draw(st.integers(1, 3 * n))
     rng = np.random.default_rng(draw(st.integers(0, 2 ** 32 - 1)))
     ea = rng.integers(0, n, m).astype(np.uint64)
     eb = rng.integers(0, n, m).astype(np.uint64)
-    maxdeg = draw(st.sampled_from([3, 4, 7]))
+    maxdeg = draw(st.sampled_from([3, 4, 7, 10, 15]))
     keep, deg = [], np.zeros(n, dtype=int)
     for k in range(m):
         a, b = int(ea[k]), int(eb[k])
@@ -122,7 +122,7 @@ def test_random_real_coupling_graphs(capi, oracle, g, R, T, beta, per_replica, p
         if graph.info.real_slots == 0:   # one |J| and no biases: the bit-sliced packed path keeps such a graph
             assert biases is None and len(set(np.abs(ej[ea != eb]))) == 1
             return
-        assert graph.info.real_slots in (4, 7)
+        assert graph.info.real_slots in (4, 7, 11, 15)
         states = capi.States(graph, seeds)
         if per_replica:
             betas = np.linspace(0.0, 2.0, R) / scale

@@ -24,7 +24,7 @@ def _random_graph(rng, n, m, maxdeg, skip=0):
 def _case(capi, oracle, ea, eb, ej, nvars, R, T, beta=None, beta_replica=None, biases=None, initial=None, slots=None):
     seeds = capi.make_seeds(77, R)
     g = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
-    assert g.kind == capi.KIND_GENERAL and g.info.real_slots == (slots or g.info.real_slots) and g.info.real_slots in (4, 7)
+    assert g.kind == capi.KIND_GENERAL and g.info.real_slots == (slots or g.info.real_slots) and g.info.real_slots in (4, 7, 11, 15)
     assert g.info.real_quantum_log2 == oracle.rj_quantise(ea, eb, ej, nvars, biases)[0]
     st = capi.States(g, seeds, initial_state=initial)
     ref_states = None if initial is None else np.tile(np.asarray(initial, dtype=np.uint8), (32 * ((R + 31) // 32), 1))
@@ -81,6 +81,30 @@ def test_random_graph_with_real_couplings_and_biases(capi, oracle, monkeypatch):
     st.do_time_steps(3, 0.8)
     _, s2 = oracle.rj_run(ea, eb, ej, n, seeds, 3, betas=[0.8] * 3, states=s_ref, t0=3)
     np.testing.assert_array_equal(st.states().astype(np.uint8), s2[:20])
+
+
+def test_degrees_up_to_15(capi, oracle, exact, monkeypatch):
+    """11 and 15 slots: three / four index nibbles, two transpositions, 128-thread workgroups -- a square lattice with second
+    neighbours (J1-J2, degree 8), a random graph of degree <= 11 and one of degree <= 15, Gaussian couplings and biases."""
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    rng = np.random.default_rng(31)
+    W, H = 20, 14
+    ids = np.arange(W * H, dtype=np.uint64).reshape(H, W)
+    nb = [np.roll(ids, -1, axis=1), np.roll(ids, -1, axis=0), np.roll(np.roll(ids, -1, axis=0), -1, axis=1),
+          np.roll(np.roll(ids, -1, axis=0), 1, axis=1)]
+    ea = np.concatenate([ids.ravel()] * 4)
+    eb = np.concatenate([n.ravel() for n in nb])
+    ej = np.concatenate([np.full(2 * W * H, 1.0), np.full(2 * W * H, 0.45)]) * rng.choice([-1.0, 1.0], 4 * W * H)
+    _case(capi, oracle, ea, eb, ej, W * H, R=40, T=5, beta=0.7, slots=11)
+    _case(capi, oracle, ea, eb, ej, W * H, R=33, T=4, beta_replica=np.linspace(0.1, 1.2, 33), biases=rng.normal(size=W * H) * 0.3, slots=11)
+    n = 400
+    for maxdeg, m, slots in ((11, 1800, 11), (15, 2600, 15)):
+        ga, gb = _random_graph(rng, n, m, maxdeg, skip=5)
+        gj, gh = rng.normal(size=len(ga)), rng.normal(size=n) * 0.4
+        deg = np.bincount(np.concatenate([ga, gb]).astype(np.int64), minlength=n).max()
+        assert deg > (7 if slots == 11 else 11)
+        _case(capi, oracle, ga, gb, gj, n, R=37, T=5, beta=0.6, biases=gh, slots=slots)
+        _case(capi, oracle, ga, gb, gj, n, R=64, T=4, beta=np.linspace(0.2, 1.5, 4), slots=slots)
 
 
 def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exact):

@@ -51,7 +51,7 @@ def test_quantisation_and_beta_scales_match_oracle(capi, oracle):
     rng = np.random.default_rng(3)
     for trial in range(20):
         n = int(rng.integers(5, 60))
-        ea, eb = _random_graph(rng, n, min(2 * n, n * (n - 1) // 2 - 1), 7)
+        ea, eb = _random_graph(rng, n, min(2 * n, n * (n - 1) // 2 - 1), 15)
         scale = 10.0 ** rng.integers(-6, 7)
         ej = rng.normal(size=len(ea)) * scale
         h = None if trial % 3 == 0 else rng.normal(size=n) * scale * 0.5
@@ -74,11 +74,11 @@ def test_eligibility_bounds(capi):
     assert capi.rj_quantise(ea, eb, np.array([1.0, -0.5, 0.25]), 4)[3]
     # one enormous bias: the common quantum would wipe out the other couplings -> not eligible (f64 CSR path)
     assert not capi.rj_quantise(ea, eb, np.array([1.0, -0.5, 0.25]), 4, np.array([1e9, 0, 0, 0]))[3]
-    # degree 8
-    hub_a = np.zeros(8, dtype=np.uint64)
-    hub_b = np.arange(1, 9, dtype=np.uint64)
-    assert not capi.rj_quantise(hub_a, hub_b, np.ones(8) * 0.7, 9)[3]
-    assert capi.rj_quantise(hub_a[:7], hub_b[:7], np.ones(7) * 0.7, 8)[3]
+    # degree 16 is one too many (four index nibbles hold 15 bonds + the own spin)
+    hub_a = np.zeros(16, dtype=np.uint64)
+    hub_b = np.arange(1, 17, dtype=np.uint64)
+    assert not capi.rj_quantise(hub_a, hub_b, np.ones(16) * 0.7, 17)[3]
+    assert capi.rj_quantise(hub_a[:15], hub_b[:15], np.ones(15) * 0.7, 16)[3]
 
 
 def test_acceptance_probability_is_exp_to_1e_minus_7(oracle):
