@@ -202,7 +202,7 @@ uint64_t isingmc_states_timestep(const isingmc_states *states);
 int isingmc_run_sampling(isingmc_states *states, double beta, size_t thermalization, size_t sampling_freq,
                          size_t n_samples, double *energies_out, uint8_t *states_out);
 
-/* ---- on-stream parallel tempering (lattice path) --------------------------------------------------
+/* ---- on-stream parallel tempering (periodic field-free lattices; replica-packed real-coupling containers) ----
  * The classical counterpart of the loop in tempering.rs:177-194 { timesteps; parallel_tempering_step }
  * with NO host synchronisation inside it: sweeps, the energy measurement, the exchange decisions
  * (same arithmetic as isingmc_host_pt_swap_round) and the relabelling of the slots' betas are all

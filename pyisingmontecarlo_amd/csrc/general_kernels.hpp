@@ -325,7 +325,8 @@ __global__ __launch_bounds__(1024) void gen_resident_kernel(
 // ------------------------------------------------------------------------------------------------
 struct PtDev {
     const double *ladder;        // beta per rung
-    const uint64_t *ladder_thr;  // lattice: {T3, T4} per rung (host-computed, exp of glibc), else nullptr
+    const uint64_t *ladder_thr;  // per rung, host-computed: lattice {T3, T4} (exp of glibc); real-coupling path: one word = its RjBeta; else nullptr
+    uint32_t thr_words;          // 64-bit words of ladder_thr per rung (2 / 1)
     uint32_t *perm;              // rung -> global slot
     const double *slot_energy;   // all slots (gathered)
     unsigned long long *counters; // [0] = round, [1] = total swaps
@@ -333,7 +334,7 @@ struct PtDev {
     uint32_t seed_lo, seed_hi;
 };
 
-__global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *__restrict__ thr_local /*{T3,T4} per local slot*/,
+__global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *__restrict__ thr_local /*thr_words words per local slot*/,
                                                        double *__restrict__ beta_local, const uint32_t apply_only)
 {
     const unsigned long long round = P.counters[0];
@@ -361,11 +362,9 @@ __global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *
         const uint32_t slot = P.perm[i];
         if (slot >= P.slot_offset && slot < P.slot_offset + P.n_local) {
             const uint32_t r = slot - P.slot_offset;
-            beta_local[r] = P.ladder[i];
-            if (P.ladder_thr) {
-                thr_local[2 * size_t(r)] = P.ladder_thr[2 * size_t(i)];
-                thr_local[2 * size_t(r) + 1] = P.ladder_thr[2 * size_t(i) + 1];
-            }
+            if (beta_local) beta_local[r] = P.ladder[i];
+            if (P.ladder_thr)
+                for (uint32_t k = 0; k < P.thr_words; k++) thr_local[size_t(P.thr_words) * r + k] = P.ladder_thr[size_t(P.thr_words) * i + k];
         }
     }
     if (threadIdx.x == 0 && !apply_only) P.counters[0] = round + 1;

@@ -2409,13 +2409,23 @@ extern "C" int isingmc_synchronize(isingmc_states *s)
     return strip_error(strip_check(s));
 }
 
+// where the exchange kernel writes a local slot's acceptance data: {T3, T4} per replica on the lattice path, the RjBeta of
+// the slot's bit position on the real-coupling path
+static uint64_t *pt_thr_local(isingmc_states *s)
+{
+    if (s->packed) return reinterpret_cast<uint64_t *>(s->d_rj_betas + s->pk_bit0);
+    return reinterpret_cast<uint64_t *>(s->d_thr);
+}
+
 extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
                                  size_t slots_per_rank, size_t world_size, uint64_t seed)
 {
     if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
-    if (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE)
-        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for periodic, field-free lattices (use the host swap step)");
+    const bool rj_ladder = s->packed && s->rj;
+    if (!rj_ladder && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
+        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for periodic, field-free lattices and for the replica-packed "
+                                         "real-coupling path (use the host swap step)");
     if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
         return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
     for (size_t i = 0; i < n_rungs; i++)
@@ -2435,6 +2445,19 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
     HIP_TRY(hipMemset(s->d_pt_counters, 0, 2 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_pt_local, 0, slots_per_rank * sizeof(double)));
     HIP_TRY(hipMemset(s->d_pt_all, 0, slots_per_rank * world_size * sizeof(double)));
+    if (rj_ladder) { // acceptance scales per rung (host arithmetic: the bits of isingmc_states_set_betas)
+        std::vector<uint64_t> thr(n_rungs);
+        for (size_t i = 0; i < n_rungs; i++) {
+            RjBeta b;
+            rj_beta(ladder_betas[i], g->rj_k, &b.shift, &b.mant);
+            std::memcpy(&thr[i], &b, sizeof b);
+        }
+        TRY(dev_alloc(&s->d_pt_ladder_thr, n_rungs));
+        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!s->d_rj_betas) TRY(dev_alloc(&s->d_rj_betas, 32 * s->groups));
+        std::vector<RjBeta> init(32 * s->groups, RjBeta{31u, 0xFFFFFFFFu}); // bits this shard does not own: accept-all, nobody reads them
+        HIP_TRY(hipMemcpy(s->d_rj_betas, init.data(), init.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
+    }
     if (lattice) { // thresholds per rung from the host's exp: bit-identical to isingmc_states_set_betas
         std::vector<uint64_t> thr(2 * n_rungs);
         for (size_t i = 0; i < n_rungs; i++) {
@@ -2445,15 +2468,14 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
         TRY(dev_alloc(&s->d_pt_ladder_thr, 2 * n_rungs));
         HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
-    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
+    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, rj_ladder ? 1u : 2u, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
                   uint32_t(slot_offset), uint32_t(s->R), uint32_t(seed), uint32_t(seed >> 32)};
     s->pt_per = slots_per_rank;
     s->pt_world = world_size;
     s->betas.assign(s->R, 0.0);
     s->has_betas = true;
     s->pt_attached = true;
-    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, reinterpret_cast<uint64_t *>(s->d_thr),
-                       s->d_beta, 1u);
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 1u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
@@ -2549,8 +2571,13 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
                            uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
                            s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
         s->meas_zero = true;
+    } else if (s->packed && s->rj) {
+        TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
+        s->meas_zero = false;
+        HIP_TRY(rj_launch_energy_from_counts(s->stream, s->d_meas, uint32_t(s->pk_bit0), uint32_t(R), g->rj_k, g->self_energy,
+                                             s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local));
     } else {
-        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path; use the host swap step");
+        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path and the real-coupling path; use the host swap step");
     }
     HIP_TRY(hipGetLastError());
     return ISINGMC_OK;
@@ -2561,8 +2588,7 @@ extern "C" int isingmc_pt_swap(isingmc_states *s)
 {
     if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
     TRY(use_device(s->g->device));
-    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, reinterpret_cast<uint64_t *>(s->d_thr),
-                       s->d_beta, 0u);
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 0u);
     HIP_TRY(hipGetLastError());
     return ISINGMC_OK;
 }

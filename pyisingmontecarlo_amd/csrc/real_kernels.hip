@@ -53,6 +53,13 @@ hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *stat
     return hipGetLastError();
 }
 
+hipError_t rj_launch_energy_from_counts(hipStream_t stream, unsigned long long *meas, uint32_t first_slot, uint32_t n, int k,
+                                        double self_energy, double *out)
+{
+    hipLaunchKernelGGL(rj_energy_from_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, meas, first_slot, n, k, self_energy, out);
+    return hipGetLastError();
+}
+
 int rj_measure_blocks_per_cu(uint32_t slots, bool bipartite, bool count_up)
 {
     int n = 0;

@@ -310,4 +310,17 @@ __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_measure_kernel(con
     }
 }
 
+// tempering on the stream: energies of the local slots from the measurement counters, E = 2^k (-c / 2) + self-loop constant
+// (the arithmetic of the host's pk_energy: the same bits); the counters are left zeroed for the next round
+__attribute__((unused)) static __global__ void rj_energy_from_counts_kernel(unsigned long long *__restrict__ meas, const uint32_t first_slot,
+                                                                            const uint32_t n, const int k, const double self_energy,
+                                                                            double *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        const long long c = (long long)meas[2 * size_t(first_slot + r)];
+        out[r] = ldexp(double(-(c / 2)), k) + self_energy;
+    }
+}
+
 } // namespace isingmc

@@ -43,6 +43,9 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
 // count_up: also the up spins (32 more registers per thread); energy-only callers pass false and leave out[2 slot + 1] alone.
 hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *state, const RjGraphDev &G, const uint32_t *site,
                              uint32_t class0_end, uint32_t scan_end, bool count_up, unsigned long long *out);
+// on-stream tempering: out[r] = energy of slot first_slot + r from the counters a measurement left in meas
+hipError_t rj_launch_energy_from_counts(hipStream_t stream, unsigned long long *meas, uint32_t first_slot, uint32_t n, int k,
+                                        double self_energy, double *out);
 // threads per workgroup of the kernels for `slots` (256, or 128 for 11 / 15 slots: their per-thread tables are 48 / 64 words)
 uint32_t rj_threads(uint32_t slots);
 // workgroups of that instantiation one CU holds (the launch is sized so that all of them are resident at once)

@@ -21,8 +21,11 @@ class HipEngine:
     def __init__(self, ea, eb, ej, nvars, device=0):
         self.graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=device)
         self.nvars = self.graph.nvars
-        # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream
-        self.supports_on_stream_pt = self.graph.kind == _capi.KIND_LATTICE2D and self.graph.info.fast_path == 0
+        # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream: periodic field-free
+        # lattices, and graphs on the replica-packed real-coupling path (whether a container is packed depends on its
+        # size: pt_attach refuses otherwise and the ladder falls back to the host swap step)
+        self.supports_on_stream_pt = ((self.graph.kind == _capi.KIND_LATTICE2D and self.graph.info.fast_path == 0) or
+                                      self.graph.info.real_slots > 0)
 
     def make_states(self, seeds, replica_range=None):
         """seeds of ALL slots + this rank's [lo, hi): group membership on the replica-packed path follows the global
@@ -118,12 +121,18 @@ class ClassicalTempering:
         self._engine = self._engine_factory()
         self._states = self._engine.make_states(np.array(self._slot_seeds, dtype=np.uint64), (self._lo, self._hi))
         self._perm = np.arange(G, dtype=np.uint32)
-        self._on_stream = bool(getattr(self._engine, "supports_on_stream_pt", False)) and self._hi > self._lo
+        import os
+        self._on_stream = (bool(getattr(self._engine, "supports_on_stream_pt", False)) and self._hi > self._lo and
+                           os.environ.get("ISINGMC_PT_HOST", "0") in ("", "0"))  # ISINGMC_PT_HOST=1: the host swap step (A/B runs)
+        if self._on_stream:
+            try:
+                self._states.pt_attach(self._betas, self._lo, self._per, self._world, self._seed)
+            except ValueError:  # e.g. a real-coupling graph too small for the packed kernels: the host swap step serves it
+                self._on_stream = False
         if self._world > 1:  # every rank must take the same path (the collective differs)
             flags = D.all_gather_f64(np.array([float(self._on_stream)]), 1, self._group)
             self._on_stream = bool(flags.min() > 0)
         if self._on_stream:
-            self._states.pt_attach(self._betas, self._lo, self._per, self._world, self._seed)
             self._pt_local, self._pt_all = self._states.pt_buffers()
             self._pt_stream = self._states.pt_stream() if self._world > 1 else None
         else:

@@ -253,3 +253,52 @@ def test_classic_ising_on_the_packed_paths_and_append(oracle, exact, monkeypatch
         start[1] = 1
         e1, ref1 = run(ea, eb, ej, N, np.array(seeds[32:], dtype=np.uint64), 3, betas=[0.6] * 3, states=start, t0=2)
         assert np.array_equal(s_all[32:], ref1[:2].astype(bool)) and np.array_equal(e_all[32:], e1)
+
+
+def test_on_stream_tempering_shards_of_a_gaussian_glass(capi, oracle, exact, monkeypatch):
+    """The multi-GPU exchange protocol of the real-coupling path with both 'ranks' on this GPU: 40 rungs of a Gaussian glass
+    cut 24 + 16 (the cut falls inside a replica group), the all-gather between pt_measure and pt_swap emulated by device
+    copies on each engine's stream.  Equal to the unsharded on-stream ladder and to the host swap step on oracle engine E."""
+    import torch
+    monkeypatch.setenv("ISINGMC_FORCE_REAL", "1")
+    W, H, G, per = 24, 16, 40, 24
+    ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)
+    ej = np.random.default_rng(12).normal(size=len(ea))
+    g = capi.Graph(ea, eb, ej, nvars=W * H)
+    seeds = capi.make_seeds(3, G)
+    betas = np.linspace(0.3, 1.5, G)
+    full = capi.States(g, seeds)
+    full.pt_attach(betas, 0, G, 1, 99)
+    shards = [capi.States(g, seeds, replica_range=(0, per)), capi.States(g, seeds, replica_range=(per, G))]
+    for k, sh in enumerate(shards):
+        sh.pt_attach(betas, per * k, per, 2, 99)
+    bufs = [sh.pt_buffers() for sh in shards]
+    streams = [sh.pt_stream() for sh in shards]
+    # the host twin: oracle engine E + isingmc_host_pt_swap_round
+    perm_ref = np.arange(G, dtype=np.uint32)
+    st_ref, swaps_ref, t = None, 0, 0
+    for rnd in range(8):
+        full.pt_time_steps(2); full.pt_measure(); full.pt_swap()
+        for sh in shards:
+            sh.pt_time_steps(2)
+            sh.pt_measure()
+        for sh in shards:
+            sh.synchronize()
+        for k in range(2):                                  # "all-gather": rank-major concatenation of the locals (per slots each)
+            with torch.cuda.stream(streams[k]):
+                bufs[k][1][:per].copy_(bufs[0][0])
+                bufs[k][1][per:].copy_(bufs[1][0])
+        for sh in shards:
+            sh.pt_swap()
+        beta_of_slot = np.empty(G)
+        beta_of_slot[perm_ref] = betas
+        e_ref, st_ref = oracle.rj_run(ea, eb, ej, W * H, seeds, 2, beta_replica=beta_of_slot, states=st_ref, t0=t)
+        t += 2
+        swaps_ref += capi.pt_swap_round(99, rnd, betas, e_ref, perm_ref)
+    perm, rounds, swaps = full.pt_state()
+    assert rounds == 8 and swaps == swaps_ref > 0 and np.array_equal(perm, perm_ref)
+    assert np.array_equal(full.states().astype(np.uint8), st_ref[:G])
+    for sh in shards:
+        p, r, s = sh.pt_state()
+        assert np.array_equal(p, perm) and r == rounds and s == swaps
+    assert np.array_equal(np.concatenate([sh.states() for sh in shards]), full.states())
