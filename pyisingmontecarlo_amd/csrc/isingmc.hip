@@ -1099,14 +1099,16 @@ static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
 }
 
 // Packed or per-replica?  The packed kernels launch once per colour class and timestep; the LDS-resident CSR kernel runs a whole
-// call in one launch with one workgroup per replica, which wins on small graphs.  Measured crossover (Gaussian glasses, 16-1024
-// replicas, tools/real_small.py, profiles/r03_real_small.txt): the packed real-coupling path is ahead from 8 000 sites on at any
-// replica count >= 16 (1.7-8x), at 4 096 sites from 256 replicas (1.5-5x), at 1 728 sites from 1 024 (2.6x), never at 1 024 sites.
-static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas)
+// call in one launch with one workgroup per replica, which wins on small graphs.  Measured (profiles/r03_real_small.txt,
+// r03_few_replicas.txt):
+//  * small graphs, 16-1024 replicas (Gaussian glasses): the packed real-coupling path is ahead from 8 000 sites on at any replica
+//    count (1.7-8x), at 4 096 sites from 256 replicas (1.5-5x), at 1 728 sites from 1 024 (2.6x), never at 1 024 sites;
+//  * big graphs, few replicas (a mostly empty 32-replica word against the per-colour CSR launches): the bit-sliced packed path is
+//    ahead from ONE replica on (1.4x; 8x at 15), the real-coupling path from ~6 (0.89x at 4, 1.5x at 8, 2.7x at 15).
+static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, size_t min_replicas_big)
 {
-    if (n_replicas < 16) return false;
-    if (!gen_resident_fits(g, n_replicas)) return true; // the per-replica alternative would be the slow per-class CSR launches
-    return g->nvars >= 8000 || (g->nvars >= 1500 && uint64_t(g->nvars) * n_replicas >= (uint64_t(1) << 20));
+    if (g->nvars >= 8000) return n_replicas >= min_replicas_big;
+    return n_replicas >= 16 && g->nvars >= 1500 && uint64_t(g->nvars) * n_replicas >= (uint64_t(1) << 20);
 }
 
 // 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
@@ -1114,13 +1116,13 @@ static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL")) {
         if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
-        return packed_worth_it(g, n_replicas) ? 2 : 0;
+        return packed_worth_it(g, n_replicas, 6) ? 2 : 0;
     }
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
     if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0 ? 1 : 0;
-    return packed_worth_it(g, n_replicas) ? 1 : 0;
+    return packed_worth_it(g, n_replicas, 1) ? 1 : 0;
 }
 
 // threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)

@@ -248,7 +248,7 @@ public:
         d["open_x"] = bool(info.open_x);
         d["open_y"] = bool(info.open_y);
         d["packed_degree"] = info.packed_degree;
-        d["real_slots"] = info.real_slots; // 4 / 7 / 11 / 15: the real-coupling packed path applies (from 16 experiments on)
+        d["real_slots"] = info.real_slots; // 4 / 7 / 11 / 15: the real-coupling packed path applies (graphs of >= 8 000 sites: from 6 experiments on)
         d["real_quantum_log2"] = info.real_quantum_log2;
         return d;
     }
@@ -466,8 +466,8 @@ public:
         st_ = std::make_shared<StatesHandle>();
         st_->graph = graph_;
         // all experiments of the constructor at once (seed i = the i-th draw of the container's rng, as add_graph would
-        // draw them one by one): the library picks its path from the count -- from 16 experiments on a graph that is not a
-        // recognised lattice runs on the replica-packed kernels -- and later add_graph calls grow that container
+        // draw them one by one): the library picks its path from the count and the graph size -- a graph that is not a
+        // recognised lattice usually runs on the replica-packed kernels (isingmc.hip packed_worth_it) -- and later add_graph calls grow that container
         const size_t n = num_experiments.value_or(1);
         drawn_.resize(n);
         check(isingmc_host_make_seeds(1, master_seed_, n, drawn_.data()));

@@ -409,7 +409,7 @@ def test_packed_path_equilibrium_vs_kaufman(capi, exact, monkeypatch):
     assert abs(mean - ref) < 4.5 * err, (mean, ref, err)
 
 
-def test_packed_path_is_selected_for_large_uniform_graphs(capi, oracle, exact):
+def test_packed_path_is_selected_for_large_uniform_graphs(capi, oracle, exact, monkeypatch):
     """No env override: >= 16 experiments on a uniform-|J| graph too big for the LDS-resident kernel take
     the replica-packed path (600x600 torus: not 64-wide, 360 000 sites), and match oracle engine D."""
     W = H = 600
@@ -422,12 +422,19 @@ def test_packed_path_is_selected_for_large_uniform_graphs(capi, oracle, exact):
     e_ref, s_ref = oracle.pk_run(ea, eb, ej, W * H, seeds, 3, betas=[0.44] * 3)
     np.testing.assert_array_equal(st.states().astype(np.uint8), s_ref[:32])
     np.testing.assert_array_equal(st.energies(), e_ref)
-    # fewer than 16 experiments: thread-per-site path (oracle engine C)
+    # Round 3: on a graph of >= 8 000 sites the packed kernels are ahead from ONE experiment on (a mostly empty 32-replica word
+    # still beats the per-replica CSR launches 1.4x, profiles/r03_few_replicas.txt): two experiments = oracle engine D too
     st2 = capi.States(g, seeds[:2])
     st2.do_time_steps(2, 0.44)
+    _, s_d = oracle.pk_run(ea, eb, ej, W * H, seeds[:2], 2, betas=[0.44] * 2)
+    np.testing.assert_array_equal(st2.states().astype(np.uint8), s_d[:2])
+    # the thread-per-site path (oracle engine C) stays selectable
+    monkeypatch.setenv("ISINGMC_DISABLE_PACKED", "1")
+    st3 = capi.States(g, seeds[:2])
+    st3.do_time_steps(2, 0.44)
     for r in range(2):
         _, s_c = oracle.gen_run(ea, eb, ej, W * H, seeds[r], [0.44] * 2)
-        np.testing.assert_array_equal(st2.states()[r].astype(np.uint8), s_c)
+        np.testing.assert_array_equal(st3.states()[r].astype(np.uint8), s_c)
 
 
 @pytest.mark.parametrize("glass", [False, True])

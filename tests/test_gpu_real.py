@@ -108,7 +108,7 @@ def test_degrees_up_to_15(capi, oracle, exact, monkeypatch):
 
 
 def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exact):
-    """Lattice.set_individual_bias (lattice.rs:104-127) on a 128 x 128 ferromagnet: from 16 experiments on the real-coupling
+    """Lattice.set_individual_bias (lattice.rs:104-127) on a 128 x 128 ferromagnet: from 6 experiments on the real-coupling
     path serves it (integer couplings quantise exactly: the energies equal the f64 energy of the configuration)."""
     import py_monte_carlo
     W = H = 128                                                     # 16 384 sites: above the LDS-resident bound
@@ -142,7 +142,7 @@ def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exa
     assert np.array_equal(ss[:, 0], s_t4[:R].astype(bool))
     for r in (1, 22):
         assert es[r, 0] == oracle.energy(ea, eb, ej, W * H, ss[r, 0].astype(np.uint8), h)
-    # below 16 experiments the same inputs run on the f64 CSR path: a different (equally valid) chain
+    # below 6 experiments the same inputs run on the f64 CSR path: a different (equally valid) chain
     e3, s3 = lat.run_monte_carlo(beta, T, 3)
     e3_ref = [oracle.gen_run(ea, eb, ej, W * H, int(sd), [beta] * T, biases=h)[0] for sd in lat.make_seeds(3)]
     np.testing.assert_allclose(e3, e3_ref, rtol=1e-12)
