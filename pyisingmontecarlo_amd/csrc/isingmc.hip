@@ -135,6 +135,7 @@ struct isingmc_states {
     uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
     bool rj = false;           // packed container on the real-coupling path (real_kernels.hpp) instead of the bit-sliced one
     RjBeta *d_rj_betas = nullptr; // per-replica acceptance scales [32 groups] (has_betas)
+    unsigned long long *d_pk_slot_thr = nullptr; // on-stream tempering on the bit-sliced packed path: T_m per slot [32 groups][PK_MAX_DEG]
     size_t n_total = 0, first = 0; // this container is the shard [first, first + R) of n_total experiments
     // persistent strip kernel (strip_kernels.hpp): halo granules, error word, tag epoch
     unsigned long long *d_halo = nullptr;
@@ -175,6 +176,7 @@ struct isingmc_states {
             if (p) (void)hipFree(p);
         if (d_tab) (void)hipFree(d_tab);
         if (d_rj_betas) (void)hipFree(d_rj_betas);
+        if (d_pk_slot_thr) (void)hipFree(d_pk_slot_thr);
         if (d_thr_mc) (void)hipFree(d_thr_mc);
         for (int b = 0; b < 2; b++) {
             for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
@@ -2415,8 +2417,19 @@ extern "C" int isingmc_synchronize(isingmc_states *s)
 // the slot's bit position on the real-coupling path
 static uint64_t *pt_thr_local(isingmc_states *s)
 {
-    if (s->packed) return reinterpret_cast<uint64_t *>(s->d_rj_betas + s->pk_bit0);
+    if (s->packed && s->rj) return reinterpret_cast<uint64_t *>(s->d_rj_betas + s->pk_bit0);
+    if (s->packed) return reinterpret_cast<uint64_t *>(s->d_pk_slot_thr); // pk_bit0 == 0 (checked at attach)
     return reinterpret_cast<uint64_t *>(s->d_thr);
+}
+
+// bit-sliced packed path: the groups' threshold tables follow the slots' new thresholds (enqueue only)
+static int pt_after_swap(isingmc_states *s)
+{
+    if (s->packed && !s->rj && s->R) {
+        hipLaunchKernelGGL(pk_tables_from_slots_kernel, dim3(unsigned(s->groups)), dim3(64), 0, s->stream, s->d_pk_slot_thr, uint32_t(s->R), s->d_tab);
+        HIP_TRY(hipGetLastError());
+    }
+    return ISINGMC_OK;
 }
 
 extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
@@ -2424,10 +2437,13 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
 {
     if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
     if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
-    const bool rj_ladder = s->packed && s->rj;
-    if (!rj_ladder && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
+    const bool rj_ladder = s->packed && s->rj, pk_ladder = s->packed && !s->rj;
+    if (!s->packed && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
         return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for periodic, field-free lattices and for the replica-packed "
-                                         "real-coupling path (use the host swap step)");
+                                         "paths (use the host swap step)");
+    // the replicas of a bit-sliced group number their ties together: a shard must hold whole groups (distributed.block_size aligns them)
+    if (pk_ladder && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
+        return fail(ISINGMC_ERR_INVALID, "a tempering shard on the replica-packed path must start and end on multiples of 32 slots");
     if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
         return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
     for (size_t i = 0; i < n_rungs; i++)
@@ -2460,6 +2476,16 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
         std::vector<RjBeta> init(32 * s->groups, RjBeta{31u, 0xFFFFFFFFu}); // bits this shard does not own: accept-all, nobody reads them
         HIP_TRY(hipMemcpy(s->d_rj_betas, init.data(), init.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
     }
+    if (pk_ladder) { // T_m per rung, m = 1 .. PK_MAX_DEG: the values pk_fill_table puts into the host-built tables
+        std::vector<uint64_t> thr(size_t(PK_MAX_DEG) * n_rungs);
+        for (size_t i = 0; i < n_rungs; i++)
+            for (uint32_t m = 1; m <= uint32_t(PK_MAX_DEG); m++) thr[i * PK_MAX_DEG + m - 1] = threshold_fixed(ladder_betas[i], 2.0 * g->jabs * double(m));
+        TRY(dev_alloc(&s->d_pt_ladder_thr, thr.size()));
+        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!s->d_pk_slot_thr) TRY(dev_alloc(&s->d_pk_slot_thr, size_t(32) * s->groups * PK_MAX_DEG));
+        HIP_TRY(hipMemset(s->d_pk_slot_thr, 0, size_t(32) * s->groups * PK_MAX_DEG * sizeof(unsigned long long)));
+        if (!s->d_tab) TRY(dev_alloc(&s->d_tab, s->groups * PK_TAB_WORDS));
+    }
     if (lattice) { // thresholds per rung from the host's exp: bit-identical to isingmc_states_set_betas
         std::vector<uint64_t> thr(2 * n_rungs);
         for (size_t i = 0; i < n_rungs; i++) {
@@ -2470,7 +2496,7 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
         TRY(dev_alloc(&s->d_pt_ladder_thr, 2 * n_rungs));
         HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
-    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, rj_ladder ? 1u : 2u, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
+    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, rj_ladder ? 1u : pk_ladder ? uint32_t(PK_MAX_DEG) : 2u, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
                   uint32_t(slot_offset), uint32_t(s->R), uint32_t(seed), uint32_t(seed >> 32)};
     s->pt_per = slots_per_rank;
     s->pt_world = world_size;
@@ -2479,6 +2505,7 @@ extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, 
     s->pt_attached = true;
     hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 1u);
     HIP_TRY(hipGetLastError());
+    TRY(pt_after_swap(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return ISINGMC_OK;
 }
@@ -2573,6 +2600,12 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
                            uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
                            s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
         s->meas_zero = true;
+    } else if (s->packed && !s->rj) {
+        TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
+        s->meas_zero = false;
+        hipLaunchKernelGGL(pk_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas, uint32_t(s->pk_bit0),
+                           uint32_t(R), g->jabs, double(int64_t(g->n_directed / 2)), g->self_energy,
+                           s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
     } else if (s->packed && s->rj) {
         TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
         s->meas_zero = false;
@@ -2592,7 +2625,7 @@ extern "C" int isingmc_pt_swap(isingmc_states *s)
     TRY(use_device(s->g->device));
     hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 0u);
     HIP_TRY(hipGetLastError());
-    return ISINGMC_OK;
+    return pt_after_swap(s);
 }
 
 // synchronises; perm_out: uint32[n_rungs] (rung -> slot)

@@ -299,4 +299,37 @@ __global__ __launch_bounds__(256) void pk_set_replica_kernel(uint32_t *__restric
     *w = (*w & ~(1u << bit)) | (v << bit);
 }
 
+// ---- tempering on the stream (isingmc_pt_* on a packed container) -------------------------------------------------------
+// Energies of the local slots from the measurement counters: E = |J| (undirected bonds - directed satisfied count) + self loops --
+// the arithmetic of the host's pk_energy, hence the same bits.
+__attribute__((unused)) static __global__ void pk_energy_from_counts_kernel(const unsigned long long *__restrict__ meas, const uint32_t first_slot,
+                                                                            const uint32_t n, const double jabs, const double half_directed,
+                                                                            const double self_energy, double *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = jabs * (half_directed - double((long long)meas[2 * size_t(first_slot + r)])) + self_energy;
+}
+
+// Threshold tables of every group from per-slot thresholds (slot_thr[slot][m - 1] = T_m(beta of the slot), written by the exchange
+// kernel): what pk_fill_table builds on the host for isingmc_states_set_betas, bit for bit.  One wavefront per group; lane r < 32 =
+// replica bit r; slots at or beyond n_owned take the last owned slot's thresholds (as the host does).
+__attribute__((unused)) static __global__ void pk_tables_from_slots_kernel(const unsigned long long *__restrict__ slot_thr, const uint32_t n_owned,
+                                                                           uint32_t *__restrict__ tabs)
+{
+    const uint32_t g = blockIdx.x, lane = threadIdx.x; // 64 threads
+    uint32_t *tab = tabs + size_t(g) * PK_TAB_WORDS;
+    const uint32_t slot = min(32u * g + (lane & 31u), n_owned - 1u);
+    for (uint32_t m = 0; m < uint32_t(PK_MAX_DEG); m++) {
+        const unsigned long long T = lane < 32 ? slot_thr[size_t(slot) * PK_MAX_DEG + m] : 0ull;
+        const uint32_t all = uint32_t(__ballot(lane < 32 && (T >> THR_BITS) != 0));
+        if (lane == 0) tab[PK_TAB_ALL + m] = all;
+        const uint32_t hi = uint32_t(T >> 32) & ((1u << N_PLANES) - 1);
+        for (int p = 0; p < N_PLANES; p++) {
+            const uint32_t w = uint32_t(__ballot(lane < 32 && ((hi >> (N_PLANES - 1 - p)) & 1u)));
+            if (lane == 0) tab[PK_TAB_TBW + m * N_PLANES + p] = w;
+        }
+        if (lane < 32) tab[PK_TAB_LO + m * 32 + lane] = uint32_t(T);
+    }
+}
+
 } // namespace isingmc

@@ -22,10 +22,10 @@ class HipEngine:
         self.graph = _capi.Graph(ea, eb, ej, nvars=nvars, device=device)
         self.nvars = self.graph.nvars
         # sweeps, measurement, exchange decisions and beta relabelling all on the engine's HIP stream: periodic field-free
-        # lattices, and graphs on the replica-packed real-coupling path (whether a container is packed depends on its
+        # lattices, and graphs on the replica-packed paths (whether a container is packed depends on the graph and its
         # size: pt_attach refuses otherwise and the ladder falls back to the host swap step)
         self.supports_on_stream_pt = ((self.graph.kind == _capi.KIND_LATTICE2D and self.graph.info.fast_path == 0) or
-                                      self.graph.info.real_slots > 0)
+                                      self.graph.kind == _capi.KIND_GENERAL)
 
     def make_states(self, seeds, replica_range=None):
         """seeds of ALL slots + this rank's [lo, hi): group membership on the replica-packed path follows the global

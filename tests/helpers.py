@@ -54,7 +54,8 @@ class OracleLatEngine:
 
 
 class OracleRjStates:
-    """Oracle engine E (real-coupling packed spec) behind the States interface the tempering host logic uses."""
+    """Oracle engine E (real-coupling packed spec) -- or, with eng.run = O.pk_run, engine D (bit-sliced packed spec) -- behind
+    the States interface the tempering host logic uses."""
 
     def __init__(self, eng, seeds, lo, hi):
         self.eng, self.all_seeds, self.lo, self.hi = eng, np.asarray(seeds, dtype=np.uint64), lo, hi
@@ -79,8 +80,8 @@ class OracleRjStates:
             kw["beta_replica"] = full
         else:
             kw["betas"] = [beta] * timesteps if np.ndim(beta) == 0 else beta
-        out = O.rj_run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, timesteps, biases=e.biases, states=self.st, t0=self.t,
-                       per_step=per_step_energies, **kw)
+        out = e.run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, timesteps, states=self.st, t0=self.t,
+                    per_step=per_step_energies, **kw, **e.extra)
         self.st = out[1]
         self.t += timesteps
         return out[2][self.lo:self.hi] if per_step_energies else None
@@ -89,7 +90,7 @@ class OracleRjStates:
         e = self.eng
         if self.st is None:
             self.do_time_steps(0, 0.0)
-        return O.rj_run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, 0, betas=[], biases=e.biases, states=self.st, t0=self.t)[0][self.lo:self.hi]
+        return e.run(e.ea, e.eb, e.ej, e.nvars, self.all_seeds, 0, betas=[], states=self.st, t0=self.t, **e.extra)[0][self.lo:self.hi]
 
     def states(self, out=None):
         res = self.st[self.lo:self.hi].astype(np.bool_)
@@ -100,8 +101,10 @@ class OracleRjStates:
 
 
 class OracleRjEngine:
-    def __init__(self, ea, eb, ej, nvars, biases=None):
+    def __init__(self, ea, eb, ej, nvars, biases=None, bit_sliced=False):
         self.ea, self.eb, self.ej, self.nvars, self.biases = ea, eb, ej, nvars, biases
+        self.run = O.pk_run if bit_sliced else O.rj_run
+        self.extra = {} if bit_sliced else {"biases": biases}
 
     def make_states(self, seeds, replica_range=None):
         lo, hi = replica_range if replica_range is not None else (0, len(seeds))

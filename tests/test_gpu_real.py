@@ -302,3 +302,63 @@ def test_on_stream_tempering_shards_of_a_gaussian_glass(capi, oracle, exact, mon
         p, r, s = sh.pt_state()
         assert np.array_equal(p, perm) and r == rounds and s == swaps
     assert np.array_equal(np.concatenate([sh.states() for sh in shards]), full.states())
+
+
+def test_on_stream_tempering_on_the_bit_sliced_packed_path(capi, oracle, exact, monkeypatch):
+    """The 3-d +-J Edwards-Anderson glass, the standard tempering workload: uniform |J| -> the bit-sliced packed path (engine D).
+    Exchange rounds on the stream (per-slot thresholds relabelled by pt_swap_kernel, the groups' bit-sliced tables rebuilt by
+    pk_tables_from_slots_kernel) against the host swap step on the oracle engine; then two group-aligned shards."""
+    import torch
+    from helpers import OracleRjEngine
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    L, G = 8, 40
+    ea, eb, _ = exact.cubic_lattice_edges(L, 1.0)
+    ej = np.random.default_rng(21).choice([-1.0, 1.0], size=len(ea))
+    runs = []
+    for factory in (None, lambda: OracleRjEngine(ea, eb, ej, L ** 3, bit_sliced=True)):
+        pt = ClassicalTempering((ea, eb, ej), seed=5, engine_factory=factory)
+        for b in np.linspace(0.2, 1.1, G):
+            pt.add_graph(float(b))
+        pt.timesteps(3)
+        pt.timesteps(14, replica_swap_freq=2)
+        states, energies = pt.timesteps_sample(12, replica_swap_freq=3, sampling_freq=4)
+        runs.append((states, energies, pt.get_permutation(), pt.get_total_swaps()))
+        if factory is None:
+            assert pt._on_stream
+    assert runs[0][3] == runs[1][3] > 0
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
+    # sharded: 64 rungs cut 32 + 32 (whole groups), the all-gather emulated by device copies on each engine's stream
+    G, per = 64, 32
+    g = capi.Graph(ea, eb, ej, nvars=L ** 3)
+    seeds = capi.make_seeds(3, G)
+    betas = np.linspace(0.2, 1.2, G)
+    full = capi.States(g, seeds)
+    full.pt_attach(betas, 0, G, 1, 99)
+    shards = [capi.States(g, seeds, replica_range=(0, per)), capi.States(g, seeds, replica_range=(per, G))]
+    for k, sh in enumerate(shards):
+        sh.pt_attach(betas, per * k, per, 2, 99)
+    bufs = [sh.pt_buffers() for sh in shards]
+    streams = [sh.pt_stream() for sh in shards]
+    for rnd in range(8):
+        full.pt_time_steps(2); full.pt_measure(); full.pt_swap()
+        for sh in shards:
+            sh.pt_time_steps(2)
+            sh.pt_measure()
+        for sh in shards:
+            sh.synchronize()
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                bufs[k][1][:per].copy_(bufs[0][0])
+                bufs[k][1][per:].copy_(bufs[1][0])
+        for sh in shards:
+            sh.pt_swap()
+    perm, rounds, swaps = full.pt_state()
+    assert rounds == 8 and swaps > 0
+    for sh in shards:
+        p, r, s = sh.pt_state()
+        assert np.array_equal(p, perm) and r == rounds and s == swaps
+    assert np.array_equal(np.concatenate([sh.states() for sh in shards]), full.states())
+    with pytest.raises(ValueError, match="multiples of 32"):
+        capi.States(g, seeds, replica_range=(0, 40)).pt_attach(betas, 0, 40, 2, 99)
