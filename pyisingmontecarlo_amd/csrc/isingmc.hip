@@ -865,6 +865,8 @@ static dim3 lat_grid(const isingmc_graph *g, uint32_t quads, size_t replicas)
 constexpr size_t MAX_GRID_Y = 32768;
 
 static int lanes_reserve(isingmc_states *s, size_t n);
+static int lanes_fork(isingmc_states *s, size_t n);
+static int lanes_join(isingmc_states *s);
 
 // replica-packed general path (defined further down)
 static int choose_packed(const isingmc_graph *g, size_t n_replicas);
@@ -1262,7 +1264,7 @@ static int pk_set_betas(isingmc_states *s)
 }
 
 // real-coupling path: one launch per colour class; a workgroup walks several 256-position blocks (it loads the log table once)
-static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t beta_stride)
+static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t beta_stride, size_t gb, size_t ge, hipStream_t stream)
 {
     const isingmc_graph *g = s->g;
     static const int target_wgs = std::max(256, env_int("ISINGMC_REAL_TARGET_WGS", 3072));
@@ -1271,17 +1273,17 @@ static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t 
         if (e == b) continue;
         const size_t threads = rj_threads(g->rj.slots);
         const size_t nblocks = (size_t(e - b) + threads - 1) / threads;
-        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
-            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+        for (size_t g0 = gb; g0 < ge; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, ge - g0);
             const size_t gx0 = std::min(nblocks, std::max<size_t>(1, (size_t(target_wgs) + ng - 1) / ng));
             const size_t per = (nblocks + gx0 - 1) / gx0, gx = (nblocks + per - 1) / per; // equal shares, no short last round
-            (void)rj_launch_sweep(dim3(unsigned(gx), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj, b, e, s->t,
+            (void)rj_launch_sweep(dim3(unsigned(gx), unsigned(ng)), stream, s->d_state + g0 * g->pk.n_pos, g->rj, b, e, s->t,
                                   s->d_keys + g0, betas + (beta_stride ? g0 * beta_stride : 0), beta_stride);
         }
     }
 }
 
-static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride)
+static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride, size_t gb, size_t ge, hipStream_t stream)
 {
     const isingmc_graph *g = s->g;
     const bool no_uni = env_flag("ISINGMC_DISABLE_PACKED_UNIFORM"); // A/B switch: results are the same either way
@@ -1291,14 +1293,14 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
         // blocks of real sites of a one-degree graph: the specialised kernel; the class's padded tail (and
         // every other graph): the general one.  tab_stride == 0 <=> one table, one beta for every replica.
         const uint32_t mid = g->pk_uni_deg && !no_uni ? g->pk_class_full[c] : b;
-        for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
-            const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
+        for (size_t g0 = gb; g0 < ge; g0 += MAX_GRID_Y) {
+            const size_t ng = std::min(MAX_GRID_Y, ge - g0);
             if (mid > b)
                 (void)pk_uni_launch_sweep(g->pk_uni_deg, tab_stride == 0, g->pk_uni_pmj, dim3((mid - b) / 1024 + ((mid - b) % 1024 != 0), unsigned(ng)),
-                                          s->stream, s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
+                                          stream, s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
                                           tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
             if (e > mid)
-                hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - mid) / 1024 + ((e - mid) % 1024 != 0), unsigned(ng)), dim3(256), 0, s->stream,
+                hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - mid) / 1024 + ((e - mid) % 1024 != 0), unsigned(ng)), dim3(256), 0, stream,
                                    s->d_state + g0 * g->pk.n_pos, g->pk, mid, e, s->t, s->d_keys + g0,
                                    tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
         }
@@ -1356,6 +1358,41 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
     std::vector<uint32_t> h_tabs;
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    // The replica groups are independent: mid-size launches (a few waves per SIMD: the 64^3 glass x 64 replicas puts ONE wave on a
+    // SIMD per colour-class launch) leave the chip idle around every kernel boundary, so the groups go to several streams and one
+    // lane's launch gap / ramp / tail overlaps the other lanes' work (as the lattice path's replica lanes).  ISINGMC_PK_STREAMS=<n> forces.
+    size_t want_lanes = 1;
+    if (!energies_per_step && s->groups >= 2) {
+        uint64_t biggest = 0;
+        for (uint32_t c = 0; c < g->n_colours; c++) biggest = std::max<uint64_t>(biggest, g->class_base[c + 1] - g->class_base[c]);
+        const uint64_t waves_per_launch = s->groups * biggest / (s->rj ? 64 : 256); // a thread decides 1 (real) / 4 (bit-sliced) positions
+        const int forced = env_int("ISINGMC_PK_STREAMS", 0);
+        if (forced > 0) want_lanes = size_t(forced);
+        // measured (tools/pk_lanes_ab.py, profiles/r03_pk_lanes_ab.txt): two lanes +7 % (2048^2 x 256) to +43 % (512^2 x 64) from ~2 000 waves per
+        // launch on, -3..-13 % below (32^3 x 64: the launches are too short for the fork / join); four lanes: worse than two almost everywhere
+        // Short calls (the 10-timestep blocks between tempering rounds) double their launch count with lanes and run into the host's
+        // launch rate sooner: 64^3 x 64 rungs went from 24.5 to 31 us per timestep; they take lanes only for long launches
+        else if (timesteps >= 64 ? waves_per_launch >= 2048 : timesteps >= 4 && waves_per_launch >= 16384) want_lanes = 2;
+        want_lanes = std::min(want_lanes, s->groups);
+    }
+    struct LaneJoin {
+        isingmc_states *s;
+        ~LaneJoin() { if (s->n_lanes > 1) (void)lanes_join(s); }
+    } lane_join{s};
+    if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
+    const size_t n_lanes = s->n_lanes, per_lane = (s->groups + n_lanes - 1) / n_lanes;
+    const auto launch_step = [&](size_t k) {
+        for (size_t lane = 0; lane < n_lanes; lane++) {
+            const size_t gb = lane * per_lane, ge = std::min(s->groups, gb + per_lane);
+            if (gb >= ge) continue;
+            hipStream_t st = n_lanes > 1 ? s->lanes[lane] : s->stream;
+            if (s->rj) {
+                if (s->has_betas) rj_launch_timestep(s, s->d_rj_betas, 32, gb, ge, st);
+                else rj_launch_timestep(s, d_rj_steps + (beta_stride ? k : 0), 0, gb, ge, st);
+            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS, gb, ge, st);
+            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0, gb, ge, st);
+        }
+    };
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
         if (!s->has_betas && s->rj && (beta_stride || k0 == 0)) {
@@ -1371,11 +1408,7 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             HIP_TRY(hipMemcpy(d_step_tabs, h_tabs.data(), h_tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
         for (size_t k = 0; k < nk && rc == ISINGMC_OK; k++) {
-            if (s->rj) {
-                if (s->has_betas) rj_launch_timestep(s, s->d_rj_betas, 32);
-                else rj_launch_timestep(s, d_rj_steps + (beta_stride ? k : 0), 0);
-            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS);
-            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0);
+            launch_step(k);
             s->t++;
             if (energies_per_step) rc = measure_enqueue(s, d_step_counts + k * CS * 2, nullptr, nullptr, /*want_up=*/false);
         }
@@ -1385,8 +1418,13 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             for (size_t k = 0; k < nk; k++)
                 for (size_t r = 0; r < R; r++)
                     energies_per_step[r * timesteps + k0 + k] = pk_energy(g, s->rj, h_step_counts[(k * CS + r + s->pk_bit0) * 2]);
-        } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) HIP_TRY(hipStreamSynchronize(s->stream));
+        } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) {
+            // the next chunk overwrites the step tables: every lane must have finished reading them
+            if (s->n_lanes > 1) { TRY(lanes_join(s)); HIP_TRY(hipStreamSynchronize(s->stream)); TRY(lanes_fork(s, want_lanes)); }
+            else HIP_TRY(hipStreamSynchronize(s->stream));
+        }
     }
+    if (s->n_lanes > 1) { const int jrc = lanes_join(s); if (rc == ISINGMC_OK) rc = jrc; }
     if (device_ms && rc == ISINGMC_OK) {
         hipError_t err = hipEventRecord(s->ev1, s->stream);
         if (err == hipSuccess) err = hipEventSynchronize(s->ev1);
