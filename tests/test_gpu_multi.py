@@ -68,3 +68,14 @@ def test_sharded_c3_ladder_matches_the_in_kernel_exchange(tmp_path):
         assert r["perm"] == res[0]["solo_perm"] and r["swaps"] == res[0]["solo_swaps"] > 0
     assert res[0]["energies"] + res[1]["energies"] == res[0]["solo_energies"]
     assert [res[0]["checksum"], res[1]["checksum"]] == res[0]["solo_checksums"]
+
+
+def test_rccl_collective_on_the_engine_stream_single_rank(tmp_path):
+    """What one GPU can execute of the RCCL path: a nccl process group beside libisingmc.so and the tempering round's
+    all_gather_into_tensor enqueued on the engine's stream (torch.cuda.ExternalStream) between measurement and exchange."""
+    out = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tests", "_nccl_world1_worker.py"), out], env=env, timeout=600) == 0
+    res = json.load(open(out))
+    assert res["perm_equal"] and res["states_equal"] and res["rounds"] == 10 and res["swaps"] == res["swaps_ref"] > 0
