@@ -192,7 +192,7 @@ def test_replica_range_is_shard_invariant_on_packed_general_graphs(mod, capi, or
     assert np.array_equal(few.states(), s[60:64])
 
 
-@pytest.mark.parametrize("kind", ["lattice", "packed_general"])
+@pytest.mark.parametrize("kind", ["lattice", "packed_general", "real_coupling"])
 def test_in_process_device_fan_out_equals_single_device(mod, exact, monkeypatch, kind):
     """The rayon fan-out of lattice.rs:192-197 over the device list (ISINGMC_DEVICES / set_devices: one host
     thread + one isingmc_states per entry).  The list 0,0 runs two blocks side by side on the one GPU here;
@@ -201,8 +201,12 @@ def test_in_process_device_fan_out_equals_single_device(mod, exact, monkeypatch,
         ea, eb, ej = exact.square_lattice_edges(256, 64, -1.0, np.random.default_rng(1))
     else:
         ea, eb, ej = exact.square_lattice_edges(120, 120, -1.0)
+        if kind == "real_coupling":                                # Gaussian couplings: the replica-packed real-coupling path
+            ej = np.random.default_rng(2).normal(size=len(ea))
     one = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=11)
     assert one.get_devices() == [0]
+    if kind == "real_coupling":
+        assert one.engine_info()["real_slots"] == 4
     monkeypatch.setenv("ISINGMC_DEVICES", "0,0,0")
     many = mod.Lattice.from_arrays(ea, eb, ej, seed_gen=11)
     assert many.get_devices() == [0, 0, 0]
