@@ -78,7 +78,10 @@ __device__ __forceinline__ uint32_t pku_neg_of(const uint2 mask)
 }
 
 template <int D, bool UB, bool PMJ>
-__global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restrict__ state, const PkGraphDev G, const PkUniHeaders H,
+#ifndef ISINGMC_PKU_WAVES
+#define ISINGMC_PKU_WAVES 8 // workgroups of 256 threads per CU the kernel is compiled for (A/B builds: 6 or 5 + ISINGMC_PKU_VKEYS)
+#endif
+__global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(uint32_t *__restrict__ state, const PkGraphDev G, const PkUniHeaders H,
                                                                const uint32_t class_begin, const uint32_t class_end,
                                                                const uint64_t t, const uint2 *__restrict__ group_keys,
                                                                const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
@@ -92,6 +95,12 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
     uint32_t *st = state + size_t(g) * G.n_pos;
     const uint32_t *tab = tabs + size_t(g) * tab_stride;
     const uint2 key = group_keys[g];
+#ifdef ISINGMC_PKU_VKEYS // A/B build: round keys 4-10 in vector registers (14 VGPRs; spills at the 64-VGPR cap of 8 waves)
+    const PhiloxVKeys vk = philox_vkeys(key);
+#define PKU_PHILOX(c) philox4x32_10(c, key, vk)
+#else
+#define PKU_PHILOX(c) philox4x32_10(c, key)
+#endif
 
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
     const uint32_t c0w = uint32_t(t), c1w = p0;
 #pragma unroll
     for (int pl = N_PLANES - 1; pl >= 0; pl--) {
-        const uint4 rnd = philox4x32_10(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)), key);
+        const uint4 rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)));
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
         uint32_t T[3];
 #pragma unroll
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
     for (int q = 0; q < 4; q++) acc[q] = sure[q] | lt[q];
     if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
         uint32_t nres = 0;
-        uint4 rnd = philox4x32_10(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES)), key);
+        uint4 rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES)));
         uint32_t lo_j[3] = {0, 0, 0};
         if constexpr (UB) {
 #pragma unroll
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
                 const uint32_t b = __ffs(mm) - 1;
                 mm &= mm - 1;
                 if (nres != 0 && (nres & 3u) == 0)
-                    rnd = philox4x32_10(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES + (nres >> 2))), key);
+                    rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES + (nres >> 2))));
                 const bool is0 = (eq[q][0] >> b) & 1u, is1 = (eq[q][1] >> b) & 1u;
                 uint32_t lo;
                 if constexpr (UB) lo = is0 ? lo_j[0] : is1 ? lo_j[1] : lo_j[2];
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_uni_kernel(uint32_t *__restri
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(own[q] ^ acc[q], st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+#undef PKU_PHILOX
 }
 
 } // namespace isingmc
