@@ -135,6 +135,19 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
 #pragma unroll
         for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, ent[q][i] << 2, 0, 0);
 
+    // The random words do not depend on the spins: the first ISINGMC_PKU_PRE planes are drawn here, between the issue of the
+    // gathers and the first use of their results, so that the memory round trip is covered by arithmetic of the wave's own
+    const uint32_t c0w = uint32_t(t), c1w = p0;
+#ifndef ISINGMC_PKU_PRE
+#define ISINGMC_PKU_PRE 0
+#endif
+    uint4 pre[ISINGMC_PKU_PRE > 0 ? ISINGMC_PKU_PRE : 1];
+#pragma unroll
+    for (int k = 0; k < ISINGMC_PKU_PRE; k++) {
+        pre[k] = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES - 1 - k)));
+        asm volatile("" : "+v"(pre[k].x), "+v"(pre[k].y), "+v"(pre[k].z), "+v"(pre[k].w));
+    }
+
     // classes
     uint32_t eq[4][3], lt[4], und[4], sure[4]; // sure: flips whatever the random numbers say
     uint32_t all_j[3];
@@ -161,10 +174,10 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
     }
 
     // bit-planes, least significant first: lt' = (~r & tb) | (~(r ^ tb) & lt), und' = und & ~(r ^ tb)
-    const uint32_t c0w = uint32_t(t), c1w = p0;
 #pragma unroll
     for (int pl = N_PLANES - 1; pl >= 0; pl--) {
-        const uint4 rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)));
+        const uint4 rnd = N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? pre[N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? N_PLANES - 1 - pl : 0]
+                                                              : PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)));
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
         uint32_t T[3];
 #pragma unroll
