@@ -2223,9 +2223,15 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
             (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device);
             // all workgroups resident at once (the runtime's occupancy figure for this instantiation), every one walks its
             // share of the blocks; a grid one round and a bit long would run its tail at a fraction of the chip
+            static std::mutex per_cu_mutex; // (the device fan-out measures from several host threads)
             static int per_cu[4][2][2] = {};
-            int &pc = per_cu[g->rj.slots == 4 ? 0 : g->rj.slots == 7 ? 1 : g->rj.slots == 11 ? 2 : 3][bip][want_up];
-            if (pc == 0) pc = std::max(1, rj_measure_blocks_per_cu(g->rj.slots, bip, want_up));
+            int pc;
+            {
+                std::lock_guard<std::mutex> lock(per_cu_mutex);
+                int &slot = per_cu[g->rj.slots == 4 ? 0 : g->rj.slots == 7 ? 1 : g->rj.slots == 11 ? 2 : 3][bip][want_up];
+                if (slot == 0) slot = std::max(1, rj_measure_blocks_per_cu(g->rj.slots, bip, want_up));
+                pc = slot;
+            }
             const size_t resident = size_t(pc) * size_t(std::max(dev_cus, 1));
             // two colour classes: the bonds from class 0 alone; class 1 is visited only for its bias terms or the up spins
             const uint32_t class0_end = bip ? uint32_t(g->class_base[1]) : 0u;
