@@ -874,6 +874,7 @@ static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first,
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
 static int pk_set_betas(isingmc_states *s);
 static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state);
+static bool resident_disabled();
 
 // random start for replicas [first, first+count)
 static int init_random(isingmc_states *s, size_t first, size_t count)
@@ -1103,16 +1104,22 @@ static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
 }
 
 // Packed or per-replica?  The packed kernels launch once per colour class and timestep; the LDS-resident CSR kernel runs a whole
-// call in one launch with one workgroup per replica, which wins on small graphs.  Measured (profiles/r03_real_small.txt,
-// r03_few_replicas.txt):
-//  * small graphs, 16-1024 replicas (Gaussian glasses): the packed real-coupling path is ahead from 8 000 sites on at any replica
-//    count (1.7-8x), at 4 096 sites from 256 replicas (1.5-5x), at 1 728 sites from 1 024 (2.6x), never at 1 024 sites;
-//  * big graphs, few replicas (a mostly empty 32-replica word against the per-colour CSR launches): the bit-sliced packed path is
-//    ahead from ONE replica on (1.4x; 8x at 15), the real-coupling path from ~6 (0.89x at 4, 1.5x at 8, 2.7x at 15).
-static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, size_t min_replicas_big)
+// call in one launch with one workgroup per replica, which wins on small graphs (they are bound by parallelism, and a word of 32
+// replicas concentrates them on few compute units).  Measured (profiles/r03_real_small.txt, r03_few_replicas.txt,
+// r03_packed_resident_experiment.txt; attempts/s of the packed path over the per-replica one):
+//  * real-coupling path, graphs the resident CSR kernel takes: 8 000 sites 1.7x at 16 replicas, 4 096 sites 1.0x at 64 and 1.5x at
+//    256, 1 728 sites 0.7x at 256 and 2.6x at 1 024, never at 1 024 sites; big graphs: 0.9x at 4 replicas, 1.5x at 8, 2.7x at 15;
+//  * bit-sliced path (a thread decides FOUR positions: a quarter of the threads): resident-size graphs 0.8x at 4 096 sites x 256,
+//    3.0x x 1 024; 0.67x at 8 000 x 256, 2.6x x 1 024; 13 824 sites 0.7x at 16 replicas, 1.2x at 64; 128^3: 1.4x at ONE replica.
+static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real_path)
 {
-    if (g->nvars >= 8000) return n_replicas >= min_replicas_big;
-    return n_replicas >= 16 && g->nvars >= 1500 && uint64_t(g->nvars) * n_replicas >= (uint64_t(1) << 20);
+    const uint64_t work = uint64_t(g->nvars) * n_replicas; // attempts per timestep
+    const bool csr_resident = gen_resident_fits(g, n_replicas) && !resident_disabled();
+    if (real_path) {
+        if (!csr_resident) return n_replicas >= 6;
+        return n_replicas >= 16 && (g->nvars >= 8000 || (g->nvars >= 1500 && work >= (uint64_t(1) << 20)));
+    }
+    return work >= (uint64_t(1) << (csr_resident ? 22 : 19));
 }
 
 // 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
@@ -1120,13 +1127,13 @@ static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL")) {
         if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
-        return packed_worth_it(g, n_replicas, 6) ? 2 : 0;
+        return packed_worth_it(g, n_replicas, true) ? 2 : 0;
     }
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
     if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0 ? 1 : 0;
-    return packed_worth_it(g, n_replicas, 1) ? 1 : 0;
+    return packed_worth_it(g, n_replicas, false) ? 1 : 0;
 }
 
 // threshold table of one group for per-replica betas (beta_of(r) for r = 0..31)

@@ -223,7 +223,7 @@ def test_classic_ising_on_the_packed_paths_and_append(oracle, exact, monkeypatch
     creates them at once, so the replica-packed kernels serve them (bit-sliced path: uniform |J|; real-coupling path:
     anything else), and add_graph grows the container -- into the open group, or opening a new one at a multiple of 32."""
     import py_monte_carlo
-    W, H = 120, 120                                               # 14 400 sites, not 64-wide: general path, above the resident bound
+    W, H = 136, 136                                               # 18 496 sites, not 64-wide: general path; x 31 experiments: past the packed paths' break-even
     N = W * H
     ea, eb, ej_u = exact.square_lattice_edges(W, H, -1.0)
     ej_g = np.random.default_rng(3).normal(size=len(ea))
