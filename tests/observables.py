@@ -111,6 +111,17 @@ def main():
     gh2 = rng.normal(size=16) * 0.4
     if deg <= 15:
         enum_case("16-spin Gaussian graph with fields", ga, gb, gj2, 16, 0.5, gh2, 512, 200, 4000, 110, env={"ISINGMC_FORCE_REAL": "1"})
+    # Sherrington-Kirkpatrick glass on 16 spins: the complete graph, degree 15 -- the four-nibble kernel of the real-coupling path
+    ka, kb = np.triu_indices(16, 1)
+    kj = rng.normal(size=len(ka)) / 4.0
+    enum_case("16-spin SK glass (complete graph)", ka.astype(np.uint64), kb.astype(np.uint64), kj, 16, 1.0, None, 512, 200, 4000, 111,
+              env={"ISINGMC_FORCE_REAL": "1"})
+    # 12-spin graph of degree <= 11 with fields: the three-nibble kernel
+    pairs11 = [(a, b) for a in range(12) for b in range(a + 1, 12)]
+    ga11 = np.array([p[0] for p in pairs11], dtype=np.uint64)
+    gb11 = np.array([p[1] for p in pairs11], dtype=np.uint64)
+    enum_case("12-spin complete graph with fields", ga11, gb11, rng.normal(size=len(pairs11)) / 3.0, 12, 0.8, rng.normal(size=12) * 0.3,
+              512, 200, 4000, 112, env={"ISINGMC_FORCE_REAL": "1"})
     zs = np.array([r["z"] for r in rows])
     summary = {"rows": len(rows), "max_abs_z": float(np.abs(zs).max()), "rms_z": float(np.sqrt((zs ** 2).mean())),
                "within_1_sigma": int((np.abs(zs) <= 1).sum()), "within_2_sigma": int((np.abs(zs) <= 2).sum()),

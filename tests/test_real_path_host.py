@@ -117,6 +117,8 @@ def test_engine_e_against_exact_enumeration_k2(oracle, exact):
     h2 = np.zeros(16)
     h2[7] = -3.0
     cases.append((ea2, eb2, ej2, 16, h2, 0.35))
+    ka, kb = np.triu_indices(14, 1)                                   # complete graph on 14 spins: degree 13, the four-nibble shape
+    cases.append((ka.astype(np.uint64), kb.astype(np.uint64), rng.normal(size=len(ka)) / 3.5, 14, None, 0.9))
     for ea, eb, ej, n, h, beta in cases:
         assert oracle.rj_eligible(ea, eb, ej, n, h)
         ex = exact.enumerate_graph(ea, eb, ej, n, beta, h)
