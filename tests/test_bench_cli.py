@@ -16,8 +16,10 @@ def test_bare_multi_gpu_invocation_spawns_ranks_without_touching_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
-    # both ranks were started (each reports for itself) and the parent relayed their failure
-    assert out.stderr.count("bench.py needs a GPU") >= 2, out.stderr[-1500:]
+    # the ranks were started (each reports for itself -- but the launcher stops the second one as soon as the first has failed, so
+    # only one message is certain) and the parent relayed their failure
+    assert out.stderr.count("bench.py needs a GPU") >= 1, out.stderr[-1500:]
+    assert "torch.distributed" in out.stderr or "ChildFailedError" in out.stderr or "local_rank" in out.stderr, out.stderr[-1500:]
 
 
 def test_gpus_must_match_world_size_under_torchrun():
