@@ -26,9 +26,11 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(path):
-            build()
+        path = os.environ.get("ISING_ORACLE_LIB")  # tests/test_host_sanitizers.py: a build with -fsanitize
+        if not path:
+            path = os.path.join(_HERE, "liboracle.so")
+            if not os.path.exists(path):
+                build()
         L = C.CDLL(path)
         L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
         L.orc_xoshiro_from_state.argtypes = [u64p, C.c_size_t, u64p]
