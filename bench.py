@@ -102,6 +102,22 @@ def traffic_from_profile():
     return d.get("hbm_bytes_per_launch") if d else None
 
 
+def copy_ceiling_gbs(torch, mib=1024, reps=20):
+    """the on-box streaming-copy ceiling, measured in this run (outside the timed region): device-to-device copy of
+    `mib` MiB, bytes read + bytes written per second (torch's own copy kernel on torch's current stream, so torch events see it)."""
+    src = torch.empty(mib << 20, dtype=torch.uint8, device="cuda").fill_(1)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    b.synchronize()
+    return 2.0 * (mib << 20) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
     """Secondary roofline: the sweep kernel is bound by vector-ALU issue cycles, not by HBM.
     achieved = VALU-busy SIMD cycles per wave of quads from the SQ counters of the same kernel -- a COMMITTED profile
@@ -204,6 +220,9 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_launch_us,
                     "launch": "one colour half-sweep of all replicas (2 kernel dispatches, one per lane)"}
+        copy_gbs = copy_ceiling_gbs(torch)
+        roofline["copy_ceiling"] = {"achieved": achieved, "peak": copy_gbs, "unit": "GB/s", "frac": achieved / copy_gbs,
+                                    "peak_source": "this run: 1 GiB device-to-device copy, read + written bytes per second"}
         sec = valu_bound(avg_launch_us, clock_ghz, R * nvars / 2 / 128 / 64)  # wave-quads: 64 lanes x 128 spins
         if sec:
             roofline["secondary"] = sec

@@ -133,6 +133,16 @@ std::shared_ptr<GraphHandle> make_graph(const EdgeArrays &E, const std::vector<d
 {
     auto h = std::make_shared<GraphHandle>();
     py::gil_scoped_release nogil;
+    // The sign of the bias term lives in the un-vendored crate (unverified convention).  The library's
+    // Hamiltonian is E = sum J s s - sum h s (a positive bias favours True); ISINGMC_COMPAT_BIAS_SIGN=-1 hands it -h, i.e.
+    // E = sum J s s + sum h s, should the crate turn out to use that sign.
+    std::vector<double> flipped;
+    const char *sign = std::getenv("ISINGMC_COMPAT_BIAS_SIGN");
+    if (biases && sign && std::atoi(sign) < 0) {
+        flipped.resize(biases->size());
+        for (size_t i = 0; i < flipped.size(); i++) flipped[i] = -(*biases)[i];
+        biases = &flipped;
+    }
     check(isingmc_graph_create(E.a.data(), E.b.data(), E.j.data(), E.a.size(), E.nvars,
                                biases ? biases->data() : nullptr, device,
                                force_general ? ISINGMC_FLAG_FORCE_GENERAL : 0u, &h->g));

@@ -586,3 +586,18 @@ def test_per_step_energies_equal_step_by_step_measurements(capi, exact, monkeypa
         b.do_time_steps(1, beta)
         np.testing.assert_allclose(eps[:, k], b.energies(), rtol=1e-12, atol=1e-9)
     assert np.array_equal(a.packed(), b.packed())
+
+
+def test_bias_sign_compat_switch(mod, monkeypatch):
+    """The bias sign is a crate-internal convention: E = sum J s s - sum h s by default (a strong positive
+    bias aligns the spins with True); ISINGMC_COMPAT_BIAS_SIGN=-1 gives E = sum J s s + sum h s -- the mirrored chain."""
+    edges = [((i, (i + 1) % 8), -0.1) for i in range(8)]
+    lat = mod.Lattice(edges, 3)
+    lat.set_global_bias(2.0)
+    e, s = lat.run_monte_carlo(5.0, 50, 4)
+    assert s.all() and np.allclose(e, -0.8 - 16.0)
+    monkeypatch.setenv("ISINGMC_COMPAT_BIAS_SIGN", "-1")
+    lat2 = mod.Lattice(edges, 3)
+    lat2.set_global_bias(2.0)
+    e2, s2 = lat2.run_monte_carlo(5.0, 50, 4)
+    assert not s2.any() and np.array_equal(e2, e)
