@@ -582,11 +582,28 @@ __device__ __forceinline__ void quad_measure(const uint32_t own_new[4], const Qu
     }
 }
 
+// A quad's new words, held back by the measuring kernel until the end of the wave (see lat_sweep_measure_kernel)
+struct PendingQuad {
+    uint32_t w[4];
+    uint32_t widx[4]; // word indices in the own plane (widx[0] * 4 = the byte offset of a vector store)
+};
+
+template <bool VEC, typename Mem>
+__device__ __forceinline__ void store_pending(const Mem &mem, const PendingQuad &p)
+{
+    if constexpr (VEC) {
+        mem.store4(p.widx[0], make_uint4(p.w[0], p.w[1], p.w[2], p.w[3]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) mem.store1(p.widx[q], p.w[q]);
+    }
+}
+
 template <bool VEC, bool PMJ, bool UNI, typename Mem, bool MEASURE = false>
 __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, const uint32_t colour, const uint64_t t, const uint2 key,
                                             const PhiloxVKeys &vk, const LatThr thr, const uint32_t *__restrict__ jn,
                                             const uint32_t jneg_uniform, const uint32_t gid, uint32_t *sat = nullptr,
-                                            uint32_t *up = nullptr)
+                                            uint32_t *up = nullptr, PendingQuad *pending = nullptr)
 {
     if constexpr (VEC && UNI && std::is_same<Mem, BufPlanes>::value) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -597,11 +614,17 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
         load_signs<PMJ>(jn, g, Q, js);
         const uint32_t widx[4] = {4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3};
         quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
-                                               vQ, mem.own_off, 0);
         if constexpr (MEASURE) {
-            const uint32_t own_new[4] = {own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]};
-            quad_measure<PMJ>(own_new, n, js, jneg_uniform, *sat, *up);
+            // NOT stored here: the vector store (buffer_store_dwordx4 with a register offset) reads its four data registers
+            // some cycles after it issues, the compiler's hazard model inserts no wait state for that form, and the counting
+            // below would overwrite them at once -- on a loaded chip a word of the quad then arrived in memory as a bit
+            // count (wrong spins from ~1500 workgroups per launch on; round 3).  The kernel stores as its last instruction.
+#pragma unroll
+            for (int q = 0; q < 4; q++) { pending->w[q] = own[q] ^ acc[q]; pending->widx[q] = widx[q]; }
+            quad_measure<PMJ>(pending->w, n, js, jneg_uniform, *sat, *up);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
+                                                   vQ, mem.own_off, 0);
         }
         return;
     }
@@ -615,15 +638,15 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
     load_quad<VEC, UNI>(mem, g, colour, Q, qy, qxw, own, n, widx);
     quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
 
-    if constexpr (VEC) {
+    if constexpr (MEASURE) { // stored by the kernel at its end, as above
+#pragma unroll
+        for (int q = 0; q < 4; q++) { pending->w[q] = own[q] ^ acc[q]; pending->widx[q] = widx[q]; }
+        quad_measure<PMJ>(pending->w, n, js, jneg_uniform, *sat, *up);
+    } else if constexpr (VEC) {
         mem.store4(widx[0], make_uint4(own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]));
     } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) mem.store1(widx[q], own[q] ^ acc[q]);
-    }
-    if constexpr (MEASURE) {
-        const uint32_t own_new[4] = {own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]};
-        quad_measure<PMJ>(own_new, n, js, jneg_uniform, *sat, *up);
     }
 }
 
@@ -645,14 +668,15 @@ __global__ __launch_bounds__(256) void lat_sweep_measure_kernel(
     const uint32_t r = blockIdx.y;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     uint32_t sat = 0, up = 0;
+    BufPlanes mem;
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
+    mem.own_off = colour * g.wpp * 4u;
+    mem.oth_off = 0;
+    PendingQuad pending;
     if (gid < g.nquads) {
-        BufPlanes mem;
-        mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(state + size_t(r) * 2 * g.wpp, 0, int(2 * g.wpp * sizeof(uint32_t)), 0x00020000);
-        mem.own_off = colour * g.wpp * 4u;
-        mem.oth_off = 0;
         const uint2 key = keys[r];
         update_quad<VEC, PMJ, UNI, BufPlanes, true>(mem, g, colour, t, key, philox_vkeys(key), thr_replica ? thr_replica[r] : thr_uniform,
-                                                    PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid, &sat, &up);
+                                                    PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid, &sat, &up, &pending);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -669,6 +693,9 @@ __global__ __launch_bounds__(256) void lat_sweep_measure_kernel(
         atomicAdd(slot, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
         atomicAdd(slot + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
+    // the quad's new words go out last (behind the barrier above: the compiler cannot hoist a store over it), so that nothing
+    // writes the store's data registers after it has issued
+    if (gid < g.nquads) store_pending<VEC>(mem, pending);
 }
 
 template <bool VEC, bool PMJ, bool UNI>

@@ -78,6 +78,23 @@ def enum_case(name, ea, eb, ej, n, beta, biases, R, therm, steps, seed, env=None
     add(name, path, beta, "|M|", m, ex["absM"], 0.0, "exact (enumeration)", steps)
 
 
+def engine_a_case(name, path, ea, eb, ej, n, beta, R, therm, steps, seed, cpu, env=None, want_m=True):
+    """No exact result: the reference is oracle engine A (the reference's algorithm) on the same couplings, its error included."""
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    g = _capi.Graph(ea, eb, ej, nvars=n)
+    e, m = gpu_run(g, R, therm, steps, beta, seed)
+    for k in (env or {}):
+        del os.environ[k]
+    Rc, thc, stc = cpu
+    t0 = time.time()
+    ec, mc = O.ref_averages(ea, eb, ej, n, O.make_seeds(seed + 1, Rc), beta, thc, stc)
+    kind = f"oracle engine A ({Rc} chains, {time.time() - t0:.0f} s)"
+    add(name, path, beta, "E", e, ec.mean(), ec.std(ddof=1) / math.sqrt(Rc), kind, steps)
+    if want_m:
+        add(name, path, beta, "|M|", m, mc.mean(), mc.std(ddof=1) / math.sqrt(Rc), kind, steps)
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "observables.json")
     # c1: 16 x 16, beta = 0.3 (BASELINE config 1; the general path's LDS-resident kernel: 16 is not 64-wide)
@@ -122,6 +139,18 @@ def main():
     gb11 = np.array([p[1] for p in pairs11], dtype=np.uint64)
     enum_case("12-spin complete graph with fields", ga11, gb11, rng.normal(size=len(pairs11)) / 3.0, 12, 0.8, rng.normal(size=12) * 0.3,
               512, 200, 4000, 112, env={"ISINGMC_FORCE_REAL": "1"})
+    # the headline lattice at its full size, away from beta_c (at beta_c a 4096^2 lattice needs ~10^7 sweeps to equilibrate):
+    # Kaufman's exact finite-torus energy; 32 replicas from the ordered start
+    lattice_case("c2 lattice 4096x4096", 4096, 0.35, 32, 300, 200, 113)
+    lattice_case("c2 lattice 4096x4096", 4096, 0.55, 32, 300, 200, 114)
+    # c5's kernel (uniform-degree replica-packed path) on a 16^3 cubic lattice at the 3-d critical point
+    ca, cb, cj = X.cubic_lattice_edges(16, -1.0)
+    engine_a_case("16^3 cubic at beta_c (c5's kernel)", "general (replica-packed bit-sliced, degree 6)", ca, cb, cj, 4096, 0.2217, 256, 3000, 10000, 115,
+                  cpu=(64, 2000, 6000), env={"ISINGMC_FORCE_PACKED": "1"})
+    # c4's kernel (+-J sign planes on the checkerboard path) on a 64 x 64 +-J glass at beta = 1
+    ga4, gb4, gj4 = X.square_lattice_edges(64, 64, 1.0, rng=np.random.default_rng(2024))
+    engine_a_case("64x64 +-J glass (c4's kernel)", "lattice (checkerboard, +-J sign planes)", ga4, gb4, gj4, 4096, 1.0, 128, 5000, 10000, 116,
+                  cpu=(64, 3000, 6000), want_m=False)
     zs = np.array([r["z"] for r in rows])
     summary = {"rows": len(rows), "max_abs_z": float(np.abs(zs).max()), "rms_z": float(np.sqrt((zs ** 2).mean())),
                "within_1_sigma": int((np.abs(zs) <= 1).sum()), "within_2_sigma": int((np.abs(zs) <= 2).sum()),

@@ -90,3 +90,45 @@ def test_multi_class_kernels_keep_their_occupancy(tmp_path):
             assert vgpr <= 72, f"{name}: {vgpr} VGPRs"
         if "ILi2E" in name:
             assert vgpr <= 65, f"{name}: {vgpr} VGPRs"
+
+
+def test_no_vector_store_data_is_overwritten_right_behind_the_store(device_asm, tmp_path):
+    """A buffer_store_dwordx3/x4 reads its data registers some cycles after it issues.  The compiler's hazard model
+    (GCNHazardRecognizer::createsVALUHazard) inserts wait states only when the store's soffset is an immediate; with a REGISTER
+    soffset it inserts none -- and on a loaded MI355X the fused sweep+measure kernel, whose bit counts overwrote the data
+    registers in the very next instruction, stored bit counts instead of spins (round 3; wrong configurations from ~1500
+    workgroups per launch on).  No kernel may write such a store's data registers within 8 instructions of it."""
+    texts = {"isingmc.hip": device_asm}
+    src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "mc_kernels.hip")
+    out = tmp_path / "mc.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    texts["mc_kernels.hip"] = out.read_text()
+    store = re.compile(r"\s(buffer_store_dwordx[34])\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
+    write = re.compile(r"(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+    stores = 0
+    for name, text in texts.items():
+        lines = text.split("\n")
+        kernel = "?"
+        for i, line in enumerate(lines):
+            m0 = re.match(r"^(_Z\w+):", line)
+            if m0:
+                kernel = m0.group(1)
+            m = store.search(line)
+            if not m or not re.match(r"s\d+$", m.group(4)):
+                continue  # immediate soffset: the compiler inserts the wait states itself
+            stores += 1
+            lo, hi = int(m.group(2)), int(m.group(3))
+            seen, j = 0, i + 1
+            while j < len(lines) and seen < 8:
+                t = lines[j].strip()
+                j += 1
+                if not t or t.startswith((";", ".")):
+                    continue
+                seen += 1
+                w = write.match(t)
+                if w and not t.startswith(("v_cmp", "v_cmpx")):
+                    a = int(w.group(2) or w.group(4))
+                    b = int(w.group(3) or w.group(4))
+                    assert b < lo or a > hi, f"{name}: {kernel[:70]}: `{t}` {seen} instruction(s) behind `{line.strip()}`"
+    assert stores >= 4, "no register-offset vector stores found: has the pattern of this test gone stale?"

@@ -35,6 +35,39 @@ def test_c4_full_size_annealing_with_energies(exact):
     assert e77[0] == e_fin[77] and np.array_equal(s77[0], s_fin[77])
 
 
+@pytest.mark.parametrize("L,R,T", [(4096, 48, 3), (1024, 256, 4), (2048, 64, 3)])
+def test_c2_energies_after_every_step_leave_the_trajectory_alone(capi, oracle, exact, L, R, T):
+    """The uniform-J lattice at sizes whose launches exceed what the chip holds at once (c2's 4096^2; 1024^2 x 256; 2048^2 x 64):
+    the run that also returns the energy after every timestep (colour-1 half-sweep fused with the measurement) must end in the
+    SAME configurations as the plain run, its last energy must be the energy of that configuration, and a few replicas are
+    compared with the oracle.  Round 3 found the fused kernel's vector store racing with the counting code behind it -- only
+    under load, so only from ~1500 workgroups per launch on, which no earlier test reached with uniform couplings."""
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(5, R)
+    ones = np.ones(L * L, dtype=np.uint8)
+    beta = 0.55
+    plain = capi.States(g, seeds, initial_state=ones)
+    plain.do_time_steps(T, beta)
+    fused = capi.States(g, seeds, initial_state=ones)
+    per_step = fused.do_time_steps(T, beta, per_step_energies=True)
+    e_plain, e_fused = plain.energies(), fused.energies()
+    assert np.array_equal(e_plain, e_fused)
+    assert np.array_equal(per_step[:, -1], e_fused)
+    assert np.array_equal(plain.magnetisations(), fused.magnetisations())
+    s_plain, s_fused = plain.states(), fused.states()
+    assert np.array_equal(s_plain, s_fused)
+    lat = oracle.Lat(L, L)
+    for r in (1, R - 1):
+        ost = lat.pack(ones)
+        want = []
+        for t in range(T):
+            lat.sweep(ost, seeds[r], t, beta)
+            want.append(lat.energy_mag(ost)[0])
+        assert np.array_equal(lat.unpack(ost), s_fused[r].astype(np.uint8))
+        assert per_step[r].tolist() == want
+
+
 def test_c5_full_size_general_path(capi, oracle, exact, monkeypatch):
     """c5: 256^3 cubic lattice, 64 replicas, forced through the general edge-list path (replica-packed kernels)."""
     L, R = 256, 64
