@@ -35,7 +35,7 @@ def test_c4_full_size_annealing_with_energies(exact):
     assert e77[0] == e_fin[77] and np.array_equal(s77[0], s_fin[77])
 
 
-@pytest.mark.parametrize("L,R,T", [(4096, 48, 3), (1024, 256, 4), (2048, 64, 3)])
+@pytest.mark.parametrize("L,R,T", [(4096, 48, 3), (1024, 256, 4), (2048, 64, 3), (4096, 32, 9)])  # T >= 8: the plain run uses two stream lanes
 def test_c2_energies_after_every_step_leave_the_trajectory_alone(capi, oracle, exact, L, R, T):
     """The uniform-J lattice at sizes whose launches exceed what the chip holds at once (c2's 4096^2; 1024^2 x 256; 2048^2 x 64):
     the run that also returns the energy after every timestep (colour-1 half-sweep fused with the measurement) must end in the

@@ -125,7 +125,9 @@ def test_bit_sliced_packed_kernels_under_load(capi, oracle, monkeypatch, kind):
     nvars = L ** 3
     g = capi.Graph(ea, eb, ej, nvars=nvars, force_general=True)
     assert g.kind == capi.KIND_GENERAL and (g.info.packed_degree == 6) == ("diluted" not in kind)
-    betas = np.array([0.2217, 0.6])
+    # five timesteps: from four on, launches of this size go out on two stream lanes (alternate replica groups)
+    T = 5 if "ferromagnet" in kind else T
+    betas = np.array([0.2217, 0.6, 0.3, 0.1, 0.45][:T])
     run = lambda seeds, T, **kw: oracle.pk_run(ea, eb, ej, nvars, seeds, T, **kw)
     for per_step in (False, True):
         _compare_groups(capi, oracle, run, g, nvars, R, T, betas, (0, 13, 31), per_step)
@@ -170,10 +172,11 @@ def test_real_coupling_kernels_under_load(capi, oracle, exact, name, slots):
     biases = rng.normal(size=nvars) * 0.3
     g = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases, force_general=True)
     assert g.kind == capi.KIND_GENERAL and g.info.real_slots == slots
-    betas = np.array([0.5, 1.5])
+    T = 5 if slots == 7 else 2          # five timesteps: the launches go out on two stream lanes
+    betas = np.array([0.5, 1.5, 0.2, 0.9, 1.1][:T])
     run = lambda seeds, T, **kw: oracle.rj_run(ea, eb, ej, nvars, seeds, T, **kw)
     for per_step in (False, True):
-        _compare_groups(capi, oracle, run, g, nvars, 256, 2, betas, (0, 7), per_step, biases=biases)
+        _compare_groups(capi, oracle, run, g, nvars, 256, T, betas, (0, 7), per_step, biases=biases)
 
 
 def test_csr_kernel_under_load(capi, oracle, exact):
@@ -198,3 +201,35 @@ def test_csr_kernel_under_load(capi, oracle, exact):
                 e_ref, s_ref = oracle.gen_run(ea, eb, ej, W * H, seeds[r], betas, biases=biases)
             assert np.array_equal(spins[r].astype(np.uint8), s_ref)
             np.testing.assert_allclose(energies[r], e_ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["lattice", "real", "packed"])
+def test_sampling_pipeline_under_load(capi, exact, monkeypatch, kind):
+    """run_monte_carlo_sampling's slab pipeline (device sweeps + copy-out of slab j on a second stream + host expansion of slab
+    j-1) with launches of thousands of workgroups and several slabs in flight: samples and energies must equal a loop of
+    do_time_steps + states()/energies() calls."""
+    rng = np.random.default_rng(3)
+    if kind == "lattice":
+        ea, eb, ej = exact.square_lattice_edges(2048, 2048, -1.0)
+        R = 24
+    elif kind == "real":
+        ea, eb, _ = exact.square_lattice_edges(1024, 512, 1.0)
+        ej = rng.normal(size=len(ea))
+        R = 128
+    else:
+        monkeypatch.setenv("ISINGMC_DISABLE_REAL", "1")
+        ea, eb, ej = _cubic_edges(64, rng)
+        R = 256
+    g = capi.Graph(ea, eb, ej, force_general=kind != "lattice")
+    seeds = capi.make_seeds(21, R)
+    therm, freq, samples, beta = 2, 2, 5, 0.6
+    monkeypatch.setenv("ISINGMC_SAMPLE_SLAB_BYTES", str(2 * R * g.state_words * 4))      # two samples per slab: 2 + 2 + 1
+    st = capi.States(g, seeds)
+    e, s = st.run_sampling(beta, therm, freq, samples)
+    assert e.shape == (R, samples) and s.shape == (R, samples, g.nvars)
+    ref = capi.States(g, seeds)
+    ref.do_time_steps(therm, beta)
+    for k in range(samples):
+        ref.do_time_steps(freq, beta)
+        assert np.array_equal(ref.energies(), e[:, k]), (kind, k)
+        assert np.array_equal(ref.states(), s[:, k]), (kind, k)
