@@ -78,17 +78,19 @@ def enum_case(name, ea, eb, ej, n, beta, biases, R, therm, steps, seed, env=None
     add(name, path, beta, "|M|", m, ex["absM"], 0.0, "exact (enumeration)", steps)
 
 
-def engine_a_case(name, path, ea, eb, ej, n, beta, R, therm, steps, seed, cpu, env=None, want_m=True):
+def engine_a_case(name, path, ea, eb, ej, n, beta, R, therm, steps, seed, cpu, env=None, want_m=True, biases=None, fast_path=None):
     """No exact result: the reference is oracle engine A (the reference's algorithm) on the same couplings, its error included."""
     for k, v in (env or {}).items():
         os.environ[k] = v
-    g = _capi.Graph(ea, eb, ej, nvars=n)
+    g = _capi.Graph(ea, eb, ej, nvars=n, biases=biases)
+    if fast_path is not None:
+        assert g.kind == _capi.KIND_LATTICE2D and g.info.fast_path == fast_path, (name, g.kind, g.info.fast_path)
     e, m = gpu_run(g, R, therm, steps, beta, seed)
     for k in (env or {}):
         del os.environ[k]
     Rc, thc, stc = cpu
     t0 = time.time()
-    ec, mc = O.ref_averages(ea, eb, ej, n, O.make_seeds(seed + 1, Rc), beta, thc, stc)
+    ec, mc = O.ref_averages(ea, eb, ej, n, O.make_seeds(seed + 1, Rc), beta, thc, stc, biases=biases)
     kind = f"oracle engine A ({Rc} chains, {time.time() - t0:.0f} s)"
     add(name, path, beta, "E", e, ec.mean(), ec.std(ddof=1) / math.sqrt(Rc), kind, steps)
     if want_m:
@@ -151,6 +153,35 @@ def main():
     ga4, gb4, gj4 = X.square_lattice_edges(64, 64, 1.0, rng=np.random.default_rng(2024))
     engine_a_case("64x64 +-J glass (c4's kernel)", "lattice (checkerboard, +-J sign planes)", ga4, gb4, gj4, 4096, 1.0, 128, 5000, 10000, 116,
                   cpu=(64, 3000, 6000), want_m=False)
+    # the multi-class checkerboard kernels (fields, open boundaries, anisotropic couplings) on a 256 x 16 lattice: their class
+    # tables are bit-exact against oracle engine B's spin-by-spin formula in the parity tests; here the resulting chain against
+    # the reference's algorithm (engine A) on the same Hamiltonian
+    W, H = 256, 16
+    mrng = np.random.default_rng(77)
+
+    def lattice_edges(jx, jy, open_x, open_y):
+        ids = np.arange(W * H, dtype=np.uint64).reshape(H, W)
+        ea_ = np.stack([ids, ids], axis=-1).reshape(-1)
+        eb_ = np.stack([np.roll(ids, -1, axis=1), np.roll(ids, -1, axis=0)], axis=-1).reshape(-1)
+        ej_ = np.stack([np.full((H, W), -jx), np.full((H, W), -jy)], axis=-1).reshape(-1)
+        keep = np.ones(len(ea_), dtype=bool)
+        if open_x:
+            keep &= ~((ea_ % W == W - 1) & (eb_ % W == 0))
+        if open_y:
+            keep &= ~((ea_ // W == H - 1) & (eb_ // W == 0))
+        return np.ascontiguousarray(ea_[keep]), np.ascontiguousarray(eb_[keep]), np.ascontiguousarray(ej_[keep])
+
+    label = "lattice (checkerboard, multi-class kernel)"
+    cpu = (64, 1500, 5000)
+    a, b, j = lattice_edges(1.0, 1.0, False, False)
+    engine_a_case("256x16 uniform field h = 0.3", label, a, b, j, W * H, 0.4, 128, 2000, 8000, 117, cpu, biases=np.full(W * H, 0.3), fast_path=1)
+    engine_a_case("256x16 random field +-0.5", label, a, b, j, W * H, 0.4, 128, 2000, 8000, 118, cpu,
+                  biases=np.where(mrng.integers(0, 2, W * H) == 1, -0.5, 0.5))
+    a, b, j = lattice_edges(1.0, 1.0, True, True)
+    engine_a_case("256x16 open boundaries", label, a, b, j, W * H, 0.4, 128, 2000, 8000, 119, cpu, fast_path=2)
+    engine_a_case("256x16 open boundaries, h = 0.4", label, a, b, j, W * H, 0.4, 128, 2000, 8000, 120, cpu, biases=np.full(W * H, 0.4))
+    a, b, j = lattice_edges(1.0, 0.4, False, False)
+    engine_a_case("256x16 anisotropic Jy = 0.4 Jx", label, a, b, j, W * H, 0.5, 128, 2000, 8000, 121, cpu)
     zs = np.array([r["z"] for r in rows])
     summary = {"rows": len(rows), "max_abs_z": float(np.abs(zs).max()), "rms_z": float(np.sqrt((zs ** 2).mean())),
                "within_1_sigma": int((np.abs(zs) <= 1).sum()), "within_2_sigma": int((np.abs(zs) <= 2).sum()),
