@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (uses the oracle: run by hand / from tests only): 4096^2 states and per-step energies against oracle engine B."""
+"""Diagnostic (lives under tests/ because it calls the oracle; run by hand: python tests/diag_c2_parity.py [L]): 4096^2 states and per-step energies against oracle engine B."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

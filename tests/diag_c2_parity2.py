@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic 2: where do per-step-energy runs leave the oracle's trajectory?  (uses the oracle: by hand only)"""
+"""Diagnostic 2: where do per-step-energy runs leave the oracle's trajectory?  (lives under tests/ because it calls the oracle; run by hand: python tests/diag_c2_parity2.py L R [plain])"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
