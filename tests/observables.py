@@ -145,6 +145,9 @@ def main():
     # Kaufman's exact finite-torus energy; 32 replicas from the ordered start
     lattice_case("c2 lattice 4096x4096", 4096, 0.35, 32, 300, 200, 113)
     lattice_case("c2 lattice 4096x4096", 4096, 0.55, 32, 300, 200, 114)
+    # closer to beta_c = 0.4407 on both sides (correlation length ~ 6 lattice spacings: still equilibrated in ~10^2 sweeps)
+    lattice_case("c2 lattice 4096x4096", 4096, 0.40, 64, 1000, 400, 122)
+    lattice_case("c2 lattice 4096x4096", 4096, 0.48, 64, 1000, 400, 123)
     # c5's kernel (uniform-degree replica-packed path) on a 16^3 cubic lattice at the 3-d critical point
     ca, cb, cj = X.cubic_lattice_edges(16, -1.0)
     engine_a_case("16^3 cubic at beta_c (c5's kernel)", "general (replica-packed bit-sliced, degree 6)", ca, cb, cj, 4096, 0.2217, 256, 3000, 10000, 115,

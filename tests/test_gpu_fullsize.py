@@ -68,6 +68,27 @@ def test_c2_energies_after_every_step_leave_the_trajectory_alone(capi, oracle, e
         assert per_step[r].tolist() == want
 
 
+def test_c2_full_size_through_the_python_api(exact):
+    """c2's 4096^2 ferromagnet through the reference's Python surface: annealing with the energy after every timestep
+    (lattice.rs:395-470) against plain annealing (lattice.rs:309-385) and against run_monte_carlo at the last stop's beta -- the
+    same configurations from all three, K1 on the returned arrays."""
+    import py_monte_carlo
+    L, R, T = 4096, 24, 6
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    lat = py_monte_carlo.Lattice.from_arrays(ea, eb, ej, seed_gen=11)
+    assert lat.engine_info()["kind"] == "lattice2d"
+    stops = [(0, 0.2), (T, 0.6)]
+    e_all, s_all = lat.run_monte_carlo_annealing_and_get_energies(stops, T, R)
+    e_fin, s_fin = lat.run_monte_carlo_annealing(stops, T, R)
+    assert e_all.shape == (R, T) and s_all.shape == (R, L * L) and s_all.dtype == np.bool_
+    assert np.array_equal(e_all[:, -1], e_fin) and np.array_equal(s_all, s_fin)
+    for r in (0, R // 2, R - 1):
+        assert e_fin[r] == _energy(ea, eb, ej, s_fin[r])
+    e_const, s_const = lat.run_monte_carlo_annealing([(0, 0.5), (T, 0.5)], T, R)
+    e_plain, s_plain = lat.run_monte_carlo(0.5, T, R)
+    assert np.array_equal(e_const, e_plain) and np.array_equal(s_const, s_plain)
+
+
 def test_c5_full_size_general_path(capi, oracle, exact, monkeypatch):
     """c5: 256^3 cubic lattice, 64 replicas, forced through the general edge-list path (replica-packed kernels)."""
     L, R = 256, 64
