@@ -611,6 +611,8 @@ static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h, const d
     return ISINGMC_OK;
 }
 
+static bool env_flag(const char *name);
+
 static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *eb, const double *ej,
                          size_t n_edges, size_t nvars, const double *biases)
 {
@@ -748,7 +750,9 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
     }
     // real-coupling packed path: whatever the bit-sliced packed path cannot take (couplings of several sizes, site
     // biases), degree <= 15, quantisation faithful (rj_quantise)
-    if (!g->packed_ok && n_pos < 0x80000000u) {
+    // (ISINGMC_FORCE_REAL=1 at graph creation builds it for graphs the bit-sliced path takes, too: the same Hamiltonian through
+    // the other acceptance rule, for cross-checks such as tools/highstat.py)
+    if ((!g->packed_ok || env_flag("ISINGMC_FORCE_REAL")) && n_pos < 0x80000000u) {
         const RjQuant Q = rj_quantise(A, nvars, biases);
         if (Q.eligible) {
             const uint32_t slots = Q.max_degree <= 4 ? 4u : Q.max_degree <= 7 ? 7u : Q.max_degree <= 11 ? 11u : 15u;
@@ -1125,7 +1129,7 @@ static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real
 // 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
 static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
-    if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL")) {
+    if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL") && (!g->packed_ok || env_flag("ISINGMC_FORCE_REAL"))) {
         if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
         return packed_worth_it(g, n_replicas, true) ? 2 : 0;
     }

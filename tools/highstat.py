@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""High-statistics check of the headline kernel at its full size: <E> of the 4096^2 ferromagnet at several beta away from beta_c
-against Kaufman's exact finite-torus energy (values from oracle/exact.py, computed once and embedded: tools/ may not import the
-oracle), 256 replicas, thousands of sweeps -- a relative standard error of ~5e-7.  Two measurement paths: energies after every
-timestep (fused sweep+measure kernel) and energies() of the plain run every few sweeps.
+"""High-statistics check at full size: <E> of the L^2 ferromagnet at several beta away from beta_c against Kaufman's exact
+finite-torus energy (values from oracle/exact.py, computed once and embedded: tools/ may not import the oracle), 256 replicas,
+thousands of sweeps -- a relative standard error of ~5e-7.  Two measurement paths: energies after every timestep and energies()
+of the plain run every few sweeps.  Every kernel family that can run this Hamiltonian:
 
-    python tools/highstat_c2.py [L] [measured-sweeps]"""
+    lattice   the checkerboard kernels (the headline path)
+    mattis    J_ij = -sigma_i sigma_j with random sigma (a gauge transform of the ferromagnet: same spectrum) -> the +-J sign-plane kernels
+    packed    the edge list forced through the general path -> replica-packed bit-sliced kernel (degree 4)
+    real      the same with ISINGMC_FORCE_REAL=1 -> replica-packed real-coupling kernel (integer log-domain acceptance)
+
+    python tools/highstat.py [L] [measured-sweeps] [lattice|mattis|packed|real]"""
 import os
 import sys
 import time
@@ -22,15 +27,25 @@ KAUFMAN = {4096: {0.30: -11819533.083156371, 0.35: -14760696.059890712, 0.40: -1
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+PATH = sys.argv[3] if len(sys.argv) > 3 else "lattice"
 R, THERM = 256, 1500
+if PATH == "real":
+    os.environ["ISINGMC_FORCE_REAL"] = "1"
+if PATH == "packed":
+    os.environ["ISINGMC_DISABLE_REAL"] = "1"
 ids = np.arange(L * L, dtype=np.uint64).reshape(L, L)
 ea = np.ascontiguousarray(np.stack([ids, ids], axis=-1).reshape(-1))
 eb = np.ascontiguousarray(np.stack([np.roll(ids, -1, axis=1), np.roll(ids, -1, axis=0)], axis=-1).reshape(-1))
-g = _capi.Graph(ea, eb, -np.ones(len(ea)))
+sigma_gauge = np.ones(L * L, dtype=np.int8)
+if PATH == "mattis":
+    sigma_gauge = np.random.default_rng(5).choice(np.array([-1, 1], dtype=np.int8), size=L * L)
+ej = -(sigma_gauge[ea.astype(np.int64)] * sigma_gauge[eb.astype(np.int64)]).astype(np.float64)
+g = _capi.Graph(ea, eb, ej, force_general=PATH in ("packed", "real"))
+print(f"path {PATH}: kind {g.kind} fast_path {g.info.fast_path} uniform_sign {g.info.uniform_sign} packed_degree {g.info.packed_degree} real_slots {g.info.real_slots}", flush=True)
 zs = []
 for beta, exact in sorted(KAUFMAN[L].items()):
     t0 = time.time()
-    start = np.ones(L * L, dtype=np.uint8) if beta > 0.4407 else None       # ordered phase: from the ordered configuration
+    start = (sigma_gauge > 0).astype(np.uint8) if beta > 0.4407 else None   # ordered phase: from the (gauge-)ordered configuration
     st = _capi.States(g, _capi.make_seeds(int(beta * 1000), R), initial_state=start)
     st.do_time_steps(THERM, beta)
     acc = np.zeros(R)
@@ -44,7 +59,7 @@ for beta, exact in sorted(KAUFMAN[L].items()):
         plain += st.energies()
         n += 1
     plain /= n
-    line = f"L={L} beta={beta:.2f} exact {exact:.1f}"
+    line = f"{PATH} L={L} beta={beta:.2f} exact {exact:.1f}"
     for name, x in (("energy after every sweep", fused), ("energies() every 10 sweeps", plain)):
         mean, sigma = x.mean(), x.std(ddof=1) / np.sqrt(R)
         z = (mean - exact) / sigma
