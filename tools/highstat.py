@@ -8,8 +8,9 @@ of the plain run every few sweeps.  Every kernel family that can run this Hamilt
     mattis    J_ij = -sigma_i sigma_j with random sigma (a gauge transform of the ferromagnet: same spectrum) -> the +-J sign-plane kernels
     packed    the edge list forced through the general path -> replica-packed bit-sliced kernel (degree 4)
     real      the same with ISINGMC_FORCE_REAL=1 -> replica-packed real-coupling kernel (integer log-domain acceptance)
+    csr       the same with both packed paths disabled -> coloured f64 CSR kernel (det_exp acceptance)
 
-    python tools/highstat.py [L] [measured-sweeps] [lattice|mattis|packed|real]"""
+    python tools/highstat.py [L] [measured-sweeps] [lattice|mattis|packed|real|csr]"""
 import os
 import sys
 import time
@@ -33,6 +34,9 @@ if PATH == "real":
     os.environ["ISINGMC_FORCE_REAL"] = "1"
 if PATH == "packed":
     os.environ["ISINGMC_DISABLE_REAL"] = "1"
+if PATH == "csr":
+    os.environ["ISINGMC_DISABLE_REAL"] = "1"
+    os.environ["ISINGMC_DISABLE_PACKED"] = "1"
 ids = np.arange(L * L, dtype=np.uint64).reshape(L, L)
 ea = np.ascontiguousarray(np.stack([ids, ids], axis=-1).reshape(-1))
 eb = np.ascontiguousarray(np.stack([np.roll(ids, -1, axis=1), np.roll(ids, -1, axis=0)], axis=-1).reshape(-1))
@@ -40,10 +44,13 @@ sigma_gauge = np.ones(L * L, dtype=np.int8)
 if PATH == "mattis":
     sigma_gauge = np.random.default_rng(5).choice(np.array([-1, 1], dtype=np.int8), size=L * L)
 ej = -(sigma_gauge[ea.astype(np.int64)] * sigma_gauge[eb.astype(np.int64)]).astype(np.float64)
-g = _capi.Graph(ea, eb, ej, force_general=PATH in ("packed", "real"))
+g = _capi.Graph(ea, eb, ej, force_general=PATH in ("packed", "real", "csr"))
 print(f"path {PATH}: kind {g.kind} fast_path {g.info.fast_path} uniform_sign {g.info.uniform_sign} packed_degree {g.info.packed_degree} real_slots {g.info.real_slots}", flush=True)
 zs = []
+only = [float(b) for b in os.environ.get("HIGHSTAT_BETAS", "").split(",") if b]
 for beta, exact in sorted(KAUFMAN[L].items()):
+    if only and beta not in only:
+        continue
     t0 = time.time()
     start = (sigma_gauge > 0).astype(np.uint8) if beta > 0.4407 else None   # ordered phase: from the (gauge-)ordered configuration
     st = _capi.States(g, _capi.make_seeds(int(beta * 1000), R), initial_state=start)
