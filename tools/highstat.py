@@ -29,7 +29,7 @@ KAUFMAN = {4096: {0.30: -11819533.083156371, 0.35: -14760696.059890712, 0.40: -1
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 PATH = sys.argv[3] if len(sys.argv) > 3 else "lattice"
-R, THERM = 256, 1500
+R, THERM = int(os.environ.get("HIGHSTAT_R", "256")), 1500
 if PATH == "real":
     os.environ["ISINGMC_FORCE_REAL"] = "1"
 if PATH == "packed":
