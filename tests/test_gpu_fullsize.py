@@ -68,6 +68,31 @@ def test_c2_energies_after_every_step_leave_the_trajectory_alone(capi, oracle, e
         assert per_step[r].tolist() == want
 
 
+@pytest.mark.parametrize("beta", [0.35, 0.55])
+def test_c2_energy_against_kaufman_at_full_size(capi, exact, beta):
+    """K3 at the benchmark's own size: <E> of the 4096^2 ferromagnet x 64 replicas against Kaufman's exact finite-torus energy
+    on both sides of beta_c, through both measurement paths (energy after every sweep; energies() of plain runs).  The
+    standard error is ~2e-6 of the energy: the store bug of round 3 stood out here by 15-100 sigma while every small test
+    passed.  Seeded, hence deterministic: the 4 sigma bound cannot flake."""
+    L, R = 4096, 64
+    ea, eb, ej = exact.square_lattice_edges(L, L, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    start = np.ones(L * L, dtype=np.uint8) if beta > 0.4407 else None
+    st = capi.States(g, capi.make_seeds(int(beta * 100), R), initial_state=start)
+    st.do_time_steps(400, beta)
+    fused = st.do_time_steps(300, beta, per_step_energies=True).mean(axis=1)
+    plain = np.zeros(R)
+    for _ in range(40):
+        st.do_time_steps(8, beta)
+        plain += st.energies()
+    plain /= 40
+    ref = exact.kaufman_energy(L, L, beta)
+    for name, x in (("fused", fused), ("plain", plain)):
+        err = x.std(ddof=1) / np.sqrt(R)
+        assert err < 1e-5 * abs(ref), (name, err)
+        assert abs(x.mean() - ref) < 4.0 * err, (name, beta, x.mean(), ref, err)
+
+
 def test_c2_full_size_through_the_python_api(exact):
     """c2's 4096^2 ferromagnet through the reference's Python surface: annealing with the energy after every timestep
     (lattice.rs:395-470) against plain annealing (lattice.rs:309-385) and against run_monte_carlo at the last stop's beta -- the
