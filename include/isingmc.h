@@ -192,6 +192,9 @@ int isingmc_get_states(isingmc_states *states, uint8_t *states_out, size_t repli
 int isingmc_get_packed_states(isingmc_states *states, uint32_t *words_out);
 /* Absolute timestep counter of the replicas (Philox counter word; persists across calls). */
 uint64_t isingmc_states_timestep(const isingmc_states *states);
+/* Sets that counter (t < 2^48): with the seeds, isingmc_states_set_state and this, a run that was stopped after t timesteps
+ * resumes on exactly the trajectory it would have followed (the reference has no equivalent: its rng state is not exposed). */
+int isingmc_states_set_timestep(isingmc_states *states, uint64_t t);
 
 /* replaces the whole sampling loop of lattice.rs:271-287 / classicising.rs:144-173:
  *   thermalization x do_time_step(beta);  n_samples x { sampling_freq x do_time_step(beta);

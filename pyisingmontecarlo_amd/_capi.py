@@ -56,6 +56,7 @@ _PROTOTYPES = {
     "isingmc_get_states": (C.c_int, [_vp, _vp, C.c_size_t]),
     "isingmc_get_packed_states": (C.c_int, [_vp, _vp]),
     "isingmc_states_timestep": (C.c_uint64, [_vp]),
+    "isingmc_states_set_timestep": (C.c_int, [_vp, C.c_uint64]),
     "isingmc_run_sampling": (C.c_int, [_vp, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
     "isingmc_pt_attach": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64]),
     "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
@@ -264,6 +265,10 @@ class States:
     @property
     def timestep(self):
         return int(lib().isingmc_states_timestep(self._h))
+
+    @timestep.setter
+    def timestep(self, t):
+        _check(lib().isingmc_states_set_timestep(self._h, C.c_uint64(int(t))))
 
     def append(self, seed, initial_state=None):
         ini = _arr(initial_state, np.uint8)

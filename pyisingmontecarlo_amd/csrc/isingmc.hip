@@ -1027,6 +1027,17 @@ extern "C" size_t isingmc_states_count(const isingmc_states *s) { return s ? s->
 
 extern "C" uint64_t isingmc_states_timestep(const isingmc_states *s) { return s ? s->t : 0; }
 
+extern "C" int isingmc_states_set_timestep(isingmc_states *s, uint64_t t)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    // the counter words hold 48 bits of t (philox.hpp ctr2: t_lo in word 0, bits 32..47 beside the colour / call index)
+    if (t >> 48) return fail(ISINGMC_ERR_INVALID, "timestep counter must be below 2^48");
+    TRY(use_device(s->g->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->t = t;
+    return ISINGMC_OK;
+}
+
 extern "C" void isingmc_states_destroy(isingmc_states *s) { delete s; }
 
 static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal);
