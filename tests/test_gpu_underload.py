@@ -233,3 +233,30 @@ def test_sampling_pipeline_under_load(capi, exact, monkeypatch, kind):
         ref.do_time_steps(freq, beta)
         assert np.array_equal(ref.energies(), e[:, k]), (kind, k)
         assert np.array_equal(ref.states(), s[:, k]), (kind, k)
+
+
+@pytest.mark.parametrize("per_step", [False, True])
+def test_more_replicas_than_one_launch_covers_on_the_streaming_path(capi, oracle, exact, per_step):
+    """33 000 replicas of a 1024 x 512 lattice (2.1 GB of spins): the streaming kernels' launches are cut at 32 768 replicas
+    (grid.y); the replicas either side of the cut against the oracle."""
+    W, H, R = 1024, 512, 33000
+    ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(6, R)
+    st = capi.States(g, seeds)
+    betas = np.array([0.4, 0.8])
+    out = st.do_time_steps(2, betas, per_step_energies=per_step)
+    energies = st.energies()
+    lat = oracle.Lat(W, H)
+    for r in (0, 32767, 32768, R - 1):
+        ref = lat.init(seeds[r])
+        want = []
+        for t, beta in enumerate(betas):
+            lat.sweep(ref, seeds[r], t, beta)
+            want.append(lat.energy_mag(ref)[0])
+        one = capi.States(g, seeds, replica_range=(r, r + 1))      # the same replica as a shard of its own
+        one.do_time_steps(2, betas)
+        assert np.array_equal(one.packed()[0], ref), r
+        assert energies[r] == want[-1] == one.energies()[0]
+        if per_step:
+            assert out[r].tolist() == want
