@@ -97,13 +97,18 @@ def test_no_vector_store_data_is_overwritten_right_behind_the_store(device_asm, 
     (GCNHazardRecognizer::createsVALUHazard) inserts wait states only when the store's soffset is an immediate; with a REGISTER
     soffset it inserts none -- and on a loaded MI355X the fused sweep+measure kernel, whose bit counts overwrote the data
     registers in the very next instruction, stored bit counts instead of spins (round 3; wrong configurations from ~1500
-    workgroups per launch on).  No kernel may write such a store's data registers within 8 instructions of it."""
+    workgroups per launch on; isolated in profiles/r03_store_hazard.txt: the window is the one instruction slot behind the store).
+    No kernel of any translation unit may write such a store's data registers within 8 instructions of it."""
     texts = {"isingmc.hip": device_asm}
-    src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "mc_kernels.hip")
-    out = tmp_path / "mc.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
-    texts["mc_kernels.hip"] = out.read_text()
+    procs = []
+    for name in ("mc_kernels.hip", "strip_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip"):   # every other translation unit
+        out = tmp_path / (name + ".s")
+        procs.append((name, out, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                                                   "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", name)],
+                                                  stderr=subprocess.DEVNULL)))
+    for name, out, proc in procs:
+        assert proc.wait() == 0, name
+        texts[name] = out.read_text()
     store = re.compile(r"\s(buffer_store_dwordx[34])\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
     write = re.compile(r"(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
     stores = 0
