@@ -230,3 +230,98 @@ def test_call_sequences(capi, oracle, exact, monkeypatch, path):
         _check(states, model, R, exact_energy)
 
     run()
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import py_monte_carlo
+    return py_monte_carlo
+
+
+CI_OPS = st.one_of(
+    st.tuples(st.just("run"), st.sampled_from(BETAS), st.integers(0, 3), st.sampled_from([None, 1.0, 0.5, 2.0, 1.37, 0.01])),
+    st.tuples(st.just("add"), st.booleans(), st.integers(0, 10 ** 6)),
+    st.tuples(st.just("sample"), st.sampled_from(BETAS), st.integers(1, 4), st.integers(0, 2), st.integers(1, 2)),
+    st.tuples(st.just("check")),
+)
+
+
+@pytest.mark.parametrize("kind", ["lattice", "general graph"])
+def test_classic_ising_call_sequences(mod, capi, oracle, exact, kind):
+    """The persistent container of classicising.rs:27-179 through the Python surface: run_monte_carlo with any nspinupdates
+    (attempts accumulate on a cursor across calls, every nvars of them run as one sweep), add_graph with and without an initial
+    state between runs (a new replica starts at the container's current timestep, its seed is the container rng's next draw),
+    sampling runs, reads -- against the model."""
+    rng0 = np.random.default_rng(5)
+    if kind == "lattice":
+        W, H = 64, 8
+        ea, eb, ej = exact.square_lattice_edges(W, H, -1.0)
+        n = W * H
+        model = LatticeModel(oracle, oracle.Lat(W, H), n)
+        exact_energy = True
+    else:
+        n = 40
+        ea = rng0.integers(0, n, 90).astype(np.uint64)
+        eb = (ea + rng0.integers(1, n, 90).astype(np.uint64)) % n
+        ej = np.round(rng0.normal(size=90), 3)
+        ea[-1], eb[-1] = n - 1, 0                                           # nvars = max index + 1
+        model = CsrModel(oracle, ea, eb, ej, n, None)
+        exact_energy = False
+    edges = [((int(a), int(b)), float(j)) for a, b, j in zip(ea, eb, ej)]
+
+    @settings(max_examples=40 * SCALE, **COMMON)
+    @given(ops=st.lists(CI_OPS, min_size=1, max_size=7), seed=st.integers(0, 2 ** 63), first=st.integers(1, 3))
+    def run(ops, seed, first):
+        ci = mod.ClassicIsing(edges, None, first, seed)
+        R = first
+        model.start(capi.make_seeds(seed, R))
+        t, pending = 0, 0
+        rng = np.random.default_rng(seed % 2 ** 32)
+
+        def sweeps(k, beta):
+            nonlocal t
+            for _ in range(k):
+                model.step(t, [beta] * R)
+                t += 1
+
+        for op in ops:
+            if op[0] == "run":
+                _, beta, T, per = op
+                nspin = None if per is None else max(1, int(per * n))
+                ci.run_monte_carlo(beta, T, nspin)
+                pending += T * (n if nspin is None else nspin)
+                sweeps(pending // n, beta)
+                pending %= n
+            elif op[0] == "add":
+                initial = rng.integers(0, 2, n).astype(bool) if op[1] else None
+                ci.add_graph(None if initial is None else [bool(x) for x in initial])
+                R += 1
+                new_seed = int(capi.make_seeds(seed, R)[-1])
+                model.seeds.append(new_seed)
+                if kind == "lattice":
+                    model.st.append(model.lat.init(new_seed) if initial is None else model.lat.pack(initial.astype(np.uint8)))
+                else:
+                    model.st.append(oracle.gen_run(ea, eb, ej, n, new_seed, [])[1] if initial is None else initial.astype(np.uint8))
+                    model.e.append(None)
+            elif op[0] == "sample":
+                _, beta, T, therm, freq = op
+                e, s = ci.run_monte_carlo_sampling(beta, T, None, None, None, None, therm, freq)
+                S = T // freq
+                assert e.shape == (R, S) and s.shape == (R, S, n)
+                sweeps(therm, beta)
+                for k in range(S):
+                    sweeps(freq, beta)
+                    for r in range(R):
+                        assert np.array_equal(s[r, k].astype(np.uint8), model.spins(r))
+            else:
+                pass
+            states, energies = ci.get_states(), ci.get_energies()
+            assert ci.get_num_graphs() == R
+            for r in range(R):
+                assert np.array_equal(states[r].astype(np.uint8), model.spins(r)), (op, r)
+                if exact_energy:
+                    assert energies[r] == model.energy(r)
+                else:
+                    np.testing.assert_allclose(energies[r], model.energy(r), rtol=1e-9, atol=1e-9)
+
+    run()
