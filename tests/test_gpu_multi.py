@@ -54,6 +54,40 @@ def test_bare_bench_invocation_spawns_its_ranks():
     assert rec["value"] > 0 and "cpu_baseline" not in rec and -1.6 < rec["energy_per_site"] < 0.0
 
 
+def test_single_gpu_bench_line_keeps_the_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's form): ONE JSON line on stdout with the contract's keys, the
+    `roofline` and `cpu_baseline` objects, and numbers that agree with each other (value x ms_per_step, achieved / peak = frac,
+    algorithmic bytes per launch = SURVEY 8d's 0.375 B per attempt x the attempts of one colour half-sweep)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["warmup"] == 5 and rec["higher_is_better"] is True
+    assert rec["vs_baseline"] is None and rec["dtype"] == "u32" and rec["data"] == "synthetic" and "workload" in rec["config"]
+    attempts_per_step = 256 * 4096 * 4096
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 / attempts_per_step - 1.0) < 1e-9
+    roof = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.2 < roof["frac"] < 1.0
+    assert roof["algorithmic_bytes_per_launch"] == 0.375 * attempts_per_step / 2
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * roof["achieved"]
+    assert roof["traffic"] is None or 0.9 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.5
+    assert 0.2 < roof["copy_ceiling"]["frac"] <= 1.2 and roof["copy_ceiling"]["peak"] > 2000.0
+    cpu = rec["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and 1e6 < cpu["value"] < 1e10 and rec["value"] > 100 * cpu["value"]
+    assert -1.6 < rec["energy_per_site"] < -1.0
+
+
 def test_sharded_c3_ladder_matches_the_in_kernel_exchange(tmp_path):
     """the sharded tempering protocol (one strip launch per round + all-gather + exchange kernel; two
     gloo ranks sharing this GPU, 2 x 32 rungs of 1024^2) against the single-rank ladder whose rounds run inside the strip
