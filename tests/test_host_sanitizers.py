@@ -59,3 +59,51 @@ def test_oracle_engines_under_asan_and_ubsan(tmp_path):
                           "-k", "not kaufman_matches_enumeration"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_python_shim_under_asan_and_ubsan(tmp_path):
+    """The pybind11 host shim (csrc/py_monte_carlo.cpp: edge ingest off the CPython objects, argument validation, bias
+    bookkeeping, device lists) rebuilt with ASan + UBSan into a scratch copy of the package, and the API-surface tests -- which
+    need no GPU -- re-run against it in a child interpreter with the ASan runtime preloaded."""
+    import sysconfig
+    pybind11 = pytest.importorskip("pybind11")
+    pkg_src = os.path.join(ROOT, "pyisingmontecarlo_amd")
+    lib = os.path.join(pkg_src, "lib", "libisingmc.so")
+    if not os.path.exists(lib):
+        pytest.skip("libisingmc.so is not built")
+    scratch = tmp_path / "site"
+    pkg = scratch / "pyisingmontecarlo_amd"
+    pkg.mkdir(parents=True)
+    for name in os.listdir(pkg_src):
+        if name.endswith(".py"):
+            shutil.copy(os.path.join(pkg_src, name), pkg / name)
+    os.symlink(os.path.join(pkg_src, "lib"), pkg / "lib")
+    shutil.copytree(os.path.join(ROOT, "py_monte_carlo"), scratch / "py_monte_carlo", ignore=shutil.ignore_patterns("__pycache__"))
+    ext = pkg / ("_py_monte_carlo" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-fno-omit-frame-pointer",
+                            "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(), "-I" + os.path.join(ROOT, "include"),
+                            "-o", str(ext), os.path.join(CSRC, "py_monte_carlo.cpp"), "-L" + os.path.join(pkg_src, "lib"), "-lisingmc",
+                            "-Wl,-rpath," + os.path.join(pkg_src, "lib")], capture_output=True, text=True, timeout=900)
+    if build.returncode != 0 and "asan" in build.stderr:
+        pytest.skip("sanitizer runtimes are not installed with this g++")
+    assert build.returncode == 0, build.stderr[-3000:]
+    runtime = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(runtime) or not os.path.exists(runtime):
+        pytest.skip("libasan.so not found")
+    # libstdc++ must be loaded at start-up too: ASan's __cxa_throw interceptor looks the real function up when it initialises,
+    # and the interpreter itself does not link the C++ runtime (the first exception of the shim would otherwise abort the child)
+    cxx = subprocess.run(["g++", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True).stdout.strip()
+    if os.path.isabs(cxx) and os.path.exists(cxx):
+        runtime = runtime + " " + cxx
+    env = dict(os.environ, LD_PRELOAD=runtime, PYTHONPATH=os.pathsep.join([str(scratch), ROOT]),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    probe = subprocess.run(["python", "-c", "import py_monte_carlo, pyisingmontecarlo_amd._py_monte_carlo as m; print(m.__file__)"],
+                           env=env, capture_output=True, text=True, timeout=600, cwd=str(scratch))     # cwd leads sys.path
+    assert probe.returncode == 0 and str(scratch) in probe.stdout, (probe.stdout + probe.stderr)[-3000:]
+    out = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu",
+                          os.path.join(ROOT, "tests", "test_api_surface.py")], env=env, capture_output=True, text=True, timeout=1500,
+                         cwd=str(scratch))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
