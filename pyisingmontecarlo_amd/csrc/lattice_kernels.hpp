@@ -578,7 +578,9 @@ __device__ __forceinline__ void quad_measure(const uint32_t own_new[4], const Qu
             a0 = o ^ n.up[q]; a1 = o ^ n.dn[q]; a2 = o ^ n.ce[q]; a3 = o ^ n.si[q];
         }
         sat += __popc(a0) + __popc(a1) + __popc(a2) + __popc(a3);
-        up += __popc(own_new[q]) + __popc(n.ce[q]);
+        // (no up-spin count: this measurement serves lattices without a field only -- E = |J| (bonds - 2 sat) -- and the
+        // magnetisation is not part of the per-timestep output; `up` stays for the signature's sake)
+        (void)up;
     }
 }
 
@@ -684,12 +686,15 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
 }
 
 constexpr uint32_t MEASURE_SLOTS = 16;
+#ifndef ISINGMC_MEASURE_WAVES
+#define ISINGMC_MEASURE_WAVES 7 // waves per SIMD the measuring kernel is compiled for (<= 72 VGPRs; it wanted 74-80 and ran at 6)
+#endif
 
 // Colour-1 half-sweep that also measures (energies after every timestep, lattice.rs:445-455): out[r * stride] +=
 // satisfied bonds, out[r * stride + 1] += up spins of replica r after this timestep -- what lat_measure_kernel
 // would count in a second pass over the planes.
 template <bool VEC, bool PMJ, bool UNI>
-__global__ __launch_bounds__(256) void lat_sweep_measure_kernel(
+__global__ __launch_bounds__(256, ISINGMC_MEASURE_WAVES) void lat_sweep_measure_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint64_t t, const uint2 *__restrict__ keys, const LatThr thr_uniform,
     const LatThr *__restrict__ thr_replica, const uint32_t *__restrict__ jneg, const uint32_t jneg_uniform,
     unsigned long long *__restrict__ out, const size_t out_stride)
@@ -712,19 +717,12 @@ __global__ __launch_bounds__(256) void lat_sweep_measure_kernel(
                                                     PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr, jneg_uniform, gid, &sat, &up, &pending);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sat += __shfl_xor(sat, off);
-        up += __shfl_xor(up, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = sat;
-        red[1][threadIdx.x >> 6] = up;
-    }
+    for (int off = 32; off > 0; off >>= 1) sat += __shfl_xor(sat, off);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = sat;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) { // the up-spin slot (slot + 1) stays zero: see quad_measure
         unsigned long long *slot = out + size_t(r) * out_stride + 2 * (blockIdx.x % MEASURE_SLOTS);
         atomicAdd(slot, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
-        atomicAdd(slot + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
     // the quad's new words go out last (behind the barrier above: the compiler cannot hoist a store over it), so that nothing
     // writes the store's data registers after it has issued

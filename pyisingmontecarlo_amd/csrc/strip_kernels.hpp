@@ -273,23 +273,17 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
         }
         if (measure) { // get_energy after this timestep (lattice.rs:454): the strips of a replica add up
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                sat += __shfl_xor(sat, off);
-                up += __shfl_xor(up, off);
-            }
-            unsigned long long s4 = sat, u4 = up;
+            for (int off = 32; off > 0; off >>= 1) sat += __shfl_xor(sat, off);
+            (void)up; // no up-spin count on lattices without a field (quad_measure): the second counter of a step stays zero
+            unsigned long long s4 = sat;
             if constexpr (NW > 1) {
                 __syncthreads(); // red[] of the previous timestep has been read
-                if (lane == 0) { red[wave] = sat; red[4 + wave] = up; }
+                if (lane == 0) red[wave] = sat;
                 __syncthreads();
                 s4 = (unsigned long long)red[0] + red[1] + red[2] + red[3];
-                u4 = (unsigned long long)red[4] + red[5] + red[6] + red[7];
             }
             if (tid == 0) {
-                if (steps_out) {
-                    atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2, s4);
-                    atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2 + 1, u4);
-                }
+                if (steps_out) atomicAdd(steps_out + (size_t(k) * n_replicas + r) * 2, s4);
                 if (exchange) { // the replica's total for this round: the last strip to arrive posts it at the replica's rung
                     const unsigned long long round = lad.round0 + (k + 1) / lad.swap_every - 1;
                     unsigned long long *cnt = lad.round_counts + size_t(round & 1) * n_replicas + r;
