@@ -1131,7 +1131,7 @@ static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real
     const uint64_t work = uint64_t(g->nvars) * n_replicas; // attempts per timestep
     const bool csr_resident = gen_resident_fits(g, n_replicas) && !resident_disabled();
     if (real_path) {
-        if (!csr_resident) return n_replicas >= 6;
+        if (!csr_resident) return n_replicas >= 2; // partial groups draw only their own replicas' Philox calls: 1.4x the CSR launches at 2, 2.0x at 4, 2.9x at 8
         return n_replicas >= 16 && (g->nvars >= 8000 || (g->nvars >= 1500 && work >= (uint64_t(1) << 20)));
     }
     return work >= (uint64_t(1) << (csr_resident ? 22 : 19));
@@ -1242,6 +1242,16 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
     }
     s->R = s->cap = s->n_total = slot + 1;
     if (initial_state) TRY(pk_set_state(s, slot, initial_state));
+    else if (s->rj && slot % 32 != 0) {
+        // real-coupling path: the bits of a group this container does not own are not simulated (rj_sweep_kernel PARTIAL), so the
+        // new replica's column holds whatever it held: it starts from its random start, like a replica appended on any other
+        // path.  (Bit-sliced path: the unused replicas of a group ARE simulated -- the group's tie numbering needs them -- and
+        // the new replica continues that trajectory.)
+        hipLaunchKernelGGL(pk_init_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state, g->pk, s->d_keys,
+                           uint32_t(slot / 32), uint32_t(slot % 32));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     return ISINGMC_OK;
 }
 
@@ -1295,12 +1305,27 @@ static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t 
         if (e == b) continue;
         const size_t threads = rj_threads(g->rj.slots);
         const size_t nblocks = (size_t(e - b) + threads - 1) / threads;
-        for (size_t g0 = gb; g0 < ge; g0 += MAX_GRID_Y) {
-            const size_t ng = std::min(MAX_GRID_Y, ge - g0);
+        // The first and the last group of the container may own only part of their 32 replica bits (few experiments, a shard
+        // cut inside a group): those groups get launches of their own that draw only the Philox calls of the owned bits.
+        const auto quads_of = [&](size_t grp, uint32_t *lo, uint32_t *hi) {
+            const size_t lo_bit = grp == 0 ? s->pk_bit0 : 0;
+            const size_t hi_bit = grp + 1 == s->groups ? (s->pk_bit0 + s->R - 1) % 32 + 1 : 32;
+            *lo = uint32_t(lo_bit / 4);
+            *hi = uint32_t((hi_bit + 3) / 4);
+        };
+        for (size_t g0 = gb; g0 < ge;) {
+            uint32_t q_lo, q_hi;
+            quads_of(g0, &q_lo, &q_hi);
+            size_t ng = 1; // extend over the following groups with the same quads (all the whole groups in the middle)
+            for (uint32_t l2, h2; g0 + ng < ge && ng < MAX_GRID_Y; ng++) {
+                quads_of(g0 + ng, &l2, &h2);
+                if (l2 != q_lo || h2 != q_hi) break;
+            }
             const size_t gx0 = std::min(nblocks, std::max<size_t>(1, (size_t(target_wgs) + ng - 1) / ng));
             const size_t per = (nblocks + gx0 - 1) / gx0, gx = (nblocks + per - 1) / per; // equal shares, no short last round
             (void)rj_launch_sweep(dim3(unsigned(gx), unsigned(ng)), stream, s->d_state + g0 * g->pk.n_pos, g->rj, b, e, s->t,
-                                  s->d_keys + g0, betas + (beta_stride ? g0 * beta_stride : 0), beta_stride);
+                                  s->d_keys + g0, betas + (beta_stride ? g0 * beta_stride : 0), beta_stride, q_lo, q_hi);
+            g0 += ng;
         }
     }
 }

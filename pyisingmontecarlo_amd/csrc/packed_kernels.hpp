@@ -194,6 +194,20 @@ __global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ sta
     state[size_t(g) * G.n_pos + p] = G.site[p] != PAD_SITE ? sel4(rnd, q) : 0u;
 }
 
+// the random start of ONE replica bit of a group (real-coupling path: a replica appended to a partly used group starts from
+// its random start -- the bits a container does not own are not simulated there, see rj_sweep_kernel PARTIAL)
+__global__ __launch_bounds__(256) void pk_init_replica_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+                                                              const uint2 *__restrict__ group_keys, const uint32_t g, const uint32_t bit)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= G.n_pos) return;
+    const uint32_t q = (p & 255u) >> 6;
+    const uint4 rnd = philox4x32_10(make_uint4(0, p - 64 * q, 0, DOM_PK_INIT), group_keys[g]);
+    const uint32_t v = G.site[p] != PAD_SITE ? (sel4(rnd, q) >> bit) & 1u : 0u;
+    uint32_t *w = state + size_t(g) * G.n_pos + p;
+    *w = (*w & ~(1u << bit)) | (v << bit);
+}
+
 // Directed satisfied-bond total and up-spin count per replica:  out[2r] += satisfied (directed),
 // out[2r+1] += up spins.  Thread = position (stride 256 inside a chunk of 8192 positions), all 32 replicas of the
 // group at once: the satisfied bonds of a position are counted bit-sliced (as in the sweep), the counts of 32

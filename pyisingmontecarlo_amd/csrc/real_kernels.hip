@@ -22,14 +22,17 @@ uint32_t rj_threads(uint32_t slots)
 }
 
 hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
-                           uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride)
+                           uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride, uint32_t q_lo, uint32_t q_hi)
 {
     rj_with_slots(G.slots, [&](auto s_c) {
         constexpr int S = decltype(s_c)::value;
         const auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, grid, dim3(RjShape<S>::THREADS), 0, stream, state, G, class_begin, real_end, t, group_keys, betas);
+            hipLaunchKernelGGL(kernel, grid, dim3(RjShape<S>::THREADS), 0, stream, state, G, class_begin, real_end, t, group_keys, betas,
+                               q_lo, q_hi);
         };
-        if (beta_stride == 0) launch(rj_sweep_kernel<S, true>); else launch(rj_sweep_kernel<S, false>);
+        const bool whole = q_lo == 0 && q_hi >= 8; // every replica bit of the groups of this launch is decided
+        if (beta_stride == 0) { if (whole) launch(rj_sweep_kernel<S, true, false>); else launch(rj_sweep_kernel<S, true, true>); }
+        else { if (whole) launch(rj_sweep_kernel<S, false, false>); else launch(rj_sweep_kernel<S, false, true>); }
     });
     return hipGetLastError();
 }

@@ -185,10 +185,15 @@ __device__ __forceinline__ uint32_t rj_index(const uint32_t (&w)[RjShape<SLOTS>:
 }
 
 // one colour class of one timestep; blockIdx.y = replica group; a workgroup walks 256-position blocks of the class
-template <int SLOTS, bool UB>
+// PARTIAL: a group of which this container owns only the replica bits 4 q_lo .. 4 q_hi - 1 (few experiments; the first / last
+// group of a shard): only the Philox calls q_lo .. q_hi - 1 are drawn and only their replicas decided -- a replica's decisions
+// depend on nothing but its own spins, beta and bit position (S7), so the bits outside are nobody's business and stay as they are.
+// The cost of a position then is ~250 vector instructions + ~21 per decided replica instead of 932.
+template <int SLOTS, bool UB, bool PARTIAL = false>
 __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
                                                               const uint32_t real_end, const uint64_t t,
-                                                              const uint2 *__restrict__ group_keys, const RjBeta *__restrict__ betas)
+                                                              const uint2 *__restrict__ group_keys, const RjBeta *__restrict__ betas,
+                                                              const uint32_t q_lo, const uint32_t q_hi)
 {
     __shared__ uint2 s_log[RJ_LOG_INTERVALS];
     __shared__ uint32_t s_x[RjShape<SLOTS>::ENTRIES * RjShape<SLOTS>::THREADS];
@@ -214,6 +219,9 @@ __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint3
         uint32_t flips = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) { // Philox call j serves replica bits 4j .. 4j+3
+            if constexpr (PARTIAL) {
+                if (uint32_t(j) < q_lo || uint32_t(j) >= q_hi) continue; // uniform over the launch
+            }
             const uint4 rnd = philox4x32_10(make_uint4(uint32_t(t), p, DOM_RJ_SWEEP, ctr2(t, 0, uint32_t(j))), key, vk);
             const uint32_t u4[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll

@@ -32,8 +32,9 @@ struct RjBeta {
 // One colour class of one timestep.  Positions [class_begin, real_end) are the real sites of the class (the padding behind
 // them is left alone); grid.y = replica groups.  betas: beta_stride == 0: one RjBeta for every replica of the launch;
 // beta_stride == 32: betas[32 g + b] for replica bit b of group g.
+// q_lo, q_hi: the Philox calls (groups of four replica bits) to decide, 0 .. 8 = all of them (see rj_sweep_kernel PARTIAL)
 hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const RjGraphDev &G, uint32_t class_begin, uint32_t real_end,
-                           uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride);
+                           uint64_t t, const uint2 *group_keys, const RjBeta *betas, uint32_t beta_stride, uint32_t q_lo = 0, uint32_t q_hi = 8);
 
 // out[2 slot] += -2 x (energy of replica slot in units of 2^k, bias terms included) as an int64 in two's complement,
 // out[2 slot + 1] += up spins; slot = 32 g + b.  class0_end: 0, or -- on a graph of exactly two colour classes -- the end

@@ -108,14 +108,15 @@ def test_replica_packed_kernels_across_two_to_the_32(capi, oracle, exact, monkey
 
 
 @pytest.mark.parametrize("size", ["resident", "streaming"])
-def test_csr_kernels_across_two_to_the_32(capi, oracle, exact, size):
+def test_csr_kernels_across_two_to_the_32(capi, oracle, exact, monkeypatch, size):
+    monkeypatch.setenv("ISINGMC_DISABLE_REAL", "1")          # (from two experiments on, a big real-coupling graph would take the packed path)
     rng = np.random.default_rng(2)
     W, H = (20, 12) if size == "resident" else (700, 300)
     ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)
     ej = rng.normal(size=len(ea))
     biases = rng.normal(size=W * H) * 0.2
     g = capi.Graph(ea, eb, ej, nvars=W * H, biases=biases, force_general=True)
-    seeds = capi.make_seeds(4, 3)                          # fewer than 6 experiments: the f64 CSR path
+    seeds = capi.make_seeds(4, 3)
     st = capi.States(g, seeds)
     start = st.states().astype(np.uint8)
     st.timestep = T0

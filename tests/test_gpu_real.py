@@ -108,7 +108,7 @@ def test_degrees_up_to_15(capi, oracle, exact, monkeypatch):
 
 
 def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exact):
-    """Lattice.set_individual_bias (lattice.rs:104-127) on a 128 x 128 ferromagnet: from 6 experiments on the real-coupling
+    """Lattice.set_individual_bias (lattice.rs:104-127) on a 128 x 128 ferromagnet: from 2 experiments on the real-coupling
     path serves it (integer couplings quantise exactly: the energies equal the f64 energy of the configuration)."""
     import py_monte_carlo
     W = H = 128                                                     # 16 384 sites: above the LDS-resident bound
@@ -142,10 +142,13 @@ def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exa
     assert np.array_equal(ss[:, 0], s_t4[:R].astype(bool))
     for r in (1, 22):
         assert es[r, 0] == oracle.energy(ea, eb, ej, W * H, ss[r, 0].astype(np.uint8), h)
-    # below 6 experiments the same inputs run on the f64 CSR path: a different (equally valid) chain
+    # few experiments: a partly used replica group (only the owned replicas' random numbers are drawn)
     e3, s3 = lat.run_monte_carlo(beta, T, 3)
-    e3_ref = [oracle.gen_run(ea, eb, ej, W * H, int(sd), [beta] * T, biases=h)[0] for sd in lat.make_seeds(3)]
-    np.testing.assert_allclose(e3, e3_ref, rtol=1e-12)
+    assert np.array_equal(e3, e_ref[:3]) and np.array_equal(s3, s_ref[:3].astype(bool))       # the same seeds: the same chains
+    # a single experiment runs on the f64 CSR path: a different (equally valid) chain
+    e1, s1 = lat.run_monte_carlo(beta, T, 1)
+    e1_ref = [oracle.gen_run(ea, eb, ej, W * H, int(sd), [beta] * T, biases=h)[0] for sd in lat.make_seeds(1)]
+    np.testing.assert_allclose(e1, e1_ref, rtol=1e-12)
 
 
 def test_per_replica_betas_on_any_shard(capi, oracle, exact, monkeypatch):
@@ -234,9 +237,14 @@ def test_classic_ising_on_the_packed_paths_and_append(oracle, exact, monkeypatch
         ci.run_monte_carlo(0.6, 2)
         _, ref = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 2, betas=[0.6] * 2)
         assert np.array_equal(ci.get_states(), ref[:31].astype(bool))
-        # replica 31 joins the open group: it takes over the chain bit 31 has been running since t = 0
+        # replica 31 joins the open group.  Bit-sliced path: it takes over the chain bit 31 has been running since t = 0 (the
+        # unused replicas of a group are simulated: its tie numbering needs them).  Real-coupling path: bits a container does
+        # not own are not simulated, and the new replica starts from its random start now (t = 2), like on any other path.
         ci.add_graph()
         seeds.append(int(oracle.make_seeds(42, 32)[-1]))
+        if run is oracle.rj_run:
+            _, start0 = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 0, betas=[])
+            ref[31] = start0[31]
         assert ci.get_num_graphs() == 32 and np.array_equal(ci.get_states()[31], ref[31].astype(bool))
         # replica 32 opens a new group, keyed by its seed, started now (t = 2); replica 33 comes with an explicit state
         ci.add_graph()

@@ -177,10 +177,16 @@ def test_real_coupling_kernels_under_load(capi, oracle, exact, name, slots):
     run = lambda seeds, T, **kw: oracle.rj_run(ea, eb, ej, nvars, seeds, T, **kw)
     for per_step in (False, True):
         _compare_groups(capi, oracle, run, g, nvars, 256, T, betas, (0, 7), per_step, biases=biases)
+    if slots in (4, 15):
+        # few experiments on a big graph: one partly used group (only the owned replicas' Philox calls are drawn), and a whole
+        # group followed by a partly used one
+        for R in (5, 39):
+            _compare_groups(capi, oracle, run, g, nvars, R, T, betas, tuple(range((R + 31) // 32)), True, biases=biases)
 
 
-def test_csr_kernel_under_load(capi, oracle, exact):
-    """S4 (f64 CSR path: fewer than 6 experiments) on a 1024^2 Gaussian glass with fields x 5 replicas: ~10 000 workgroups per launch."""
+def test_csr_kernel_under_load(capi, oracle, exact, monkeypatch):
+    """S4 (f64 CSR path; the real-coupling path switched off) on a 1024^2 Gaussian glass with fields x 5 replicas: ~10 000 workgroups per launch."""
+    monkeypatch.setenv("ISINGMC_DISABLE_REAL", "1")
     W = H = 1024
     rng = np.random.default_rng(4)
     ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)

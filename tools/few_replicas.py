@@ -19,7 +19,7 @@ cases = [("128^3 uniform J (bit-sliced packed path)", ea3, eb3, ej3, {"ISINGMC_F
          ("2048^2 gaussian (real-coupling packed path)", ea2, eb2, rng.normal(size=len(ea2)), {"ISINGMC_FORCE_REAL": "1"}, {"ISINGMC_DISABLE_REAL": "1"}, False)]
 for name, ea, eb, ej, on, off, force_general in cases:
     n = int(max(ea.max(), eb.max())) + 1
-    for R in (1, 2, 4, 8, 15):
+    for R in (1, 2, 3, 4, 6, 8, 15, 24, 33, 40):
         out = []
         for env in (off, on):
             os.environ.update(env)
