@@ -242,11 +242,29 @@ __global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restric
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t GEN_RESIDENT_MAX_BYTES = 32 * 1024;
 
-template <typename WT>
+// LDS words the staged variant needs behind the state words (see gen_resident_kernel STAGE); edges2 = directed edges
+// stage: 1 = everything, 2 = the topology only (row pointers, site ids, neighbour positions: the links of the dependent chain;
+// couplings and biases stay in global memory, their addresses do not depend on loaded data)
+__host__ __device__ inline uint32_t gen_stage_words(uint32_t n_pos, uint32_t edges2, bool has_bias, uint32_t w_bytes, int stage)
+{
+    uint32_t off = ((n_pos / 32) + 1u) & ~1u;             // state words, then 8-byte alignment
+    if (stage == 1) {
+        if (has_bias) off += 2 * n_pos;                    // f64 bias per position
+        off += edges2 * (w_bytes / 4);                     // couplings (f32 or f64)
+        off = (off + 1u) & ~1u;
+    }
+    return off + (n_pos + 1) + n_pos + edges2;             // rowptr, site, nbr
+}
+
+// STAGE: the graph itself (row pointers, neighbour positions, couplings, biases, site ids) is copied into LDS once per launch.
+// A timestep of a small graph is a chain of DEPENDENT loads per colour class -- site -> row pointer -> neighbour -> spin word --
+// and from global memory each link costs an L2 round trip although nothing but the spins ever changes: 2.2 us per timestep for
+// 16 x 16 (c1).  Same arithmetic in the same order: bit-identical.
+template <typename WT, int STAGE>
 __global__ __launch_bounds__(1024) void gen_resident_kernel(
     uint32_t *__restrict__ state, const GenGraphDev G, const uint64_t t0, const uint32_t timesteps,
     const uint2 *__restrict__ keys, const double *__restrict__ beta_steps, const uint32_t beta_stride,
-    const double *__restrict__ beta_replica, double *__restrict__ energies_out, const double self_energy)
+    const double *__restrict__ beta_replica, double *__restrict__ energies_out, const double self_energy, const uint32_t edges2)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t st[];
     __shared__ double red[16];
@@ -254,7 +272,30 @@ __global__ __launch_bounds__(1024) void gen_resident_kernel(
     uint32_t *mine = state + size_t(r) * G.n_words;
     for (uint32_t i = tid; i < G.n_words; i += nthreads) st[i] = mine[i];
     const uint2 key = keys[r];
+    GenGraphDev L = G;                                     // the arrays the loops below read: global, or their LDS copies
     const WT *w = static_cast<const WT *>(G.w);
+    if constexpr (STAGE != 0) {
+        uint32_t off = (G.n_words + 1u) & ~1u;
+        if constexpr (STAGE == 1) {
+            double *s_bias = reinterpret_cast<double *>(st + off);
+            if (G.bias) off += 2 * G.n_pos;
+            WT *s_w = reinterpret_cast<WT *>(st + off);
+            off += edges2 * uint32_t(sizeof(WT) / 4);
+            off = (off + 1u) & ~1u;
+            if (G.bias)
+                for (uint32_t i = tid; i < G.n_pos; i += nthreads) s_bias[i] = G.bias[i];
+            for (uint32_t i = tid; i < edges2; i += nthreads) s_w[i] = w[i];
+            L.bias = G.bias ? s_bias : nullptr;
+            w = s_w;
+        }
+        uint32_t *s_rowptr = st + off;
+        uint32_t *s_site = s_rowptr + G.n_pos + 1;
+        uint32_t *s_nbr = s_site + G.n_pos;
+        for (uint32_t i = tid; i <= G.n_pos; i += nthreads) s_rowptr[i] = G.rowptr[i];
+        for (uint32_t i = tid; i < G.n_pos; i += nthreads) s_site[i] = G.site[i];
+        for (uint32_t i = tid; i < edges2; i += nthreads) s_nbr[i] = G.nbr[i];
+        L.rowptr = s_rowptr; L.site = s_site; L.nbr = s_nbr;
+    }
     __syncthreads();
     for (uint32_t k = 0; k < timesteps; k++) {
         const uint64_t t = t0 + k;
@@ -262,17 +303,17 @@ __global__ __launch_bounds__(1024) void gen_resident_kernel(
         for (uint32_t c = 0; c < G.n_colours; c++) {
             const uint32_t begin = G.class_base[c], end = G.class_base[c + 1];
             for (uint32_t p = begin + tid; p < end; p += nthreads) { // whole waves: class sizes are multiples of 64
-                const uint32_t site = G.site[p];
+                const uint32_t site = L.site[p];
                 bool flip = false;
                 if (site != PAD_SITE) {
                     double field = 0.0;
-                    for (uint32_t e = G.rowptr[p], ee = G.rowptr[p + 1]; e < ee; e++) {
-                        const uint32_t q = G.nbr[e];
+                    for (uint32_t e = L.rowptr[p], ee = L.rowptr[p + 1]; e < ee; e++) {
+                        const uint32_t q = L.nbr[e];
                         const double j = double(w[e]);
                         field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
                     }
                     const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
-                    const double dE = 2.0 * si * ((G.bias ? G.bias[p] : 0.0) - field);
+                    const double dE = 2.0 * si * ((L.bias ? L.bias[p] : 0.0) - field);
                     flip = dE <= 0.0;
                     if (!flip) {
                         const uint4 rnd = philox4x32_10(make_uint4(uint32_t(t), site >> 1, ctr2(t, 0, 0), DOM_GEN_SWEEP), key);
@@ -292,15 +333,15 @@ __global__ __launch_bounds__(1024) void gen_resident_kernel(
         if (energies_out) {
             double e = 0.0;
             for (uint32_t p = tid; p < G.n_pos; p += nthreads) {
-                if (G.site[p] == PAD_SITE) continue;
+                if (L.site[p] == PAD_SITE) continue;
                 double field = 0.0;
-                for (uint32_t ed = G.rowptr[p], ee = G.rowptr[p + 1]; ed < ee; ed++) {
-                    const uint32_t q = G.nbr[ed];
+                for (uint32_t ed = L.rowptr[p], ee = L.rowptr[p + 1]; ed < ee; ed++) {
+                    const uint32_t q = L.nbr[ed];
                     const double j = double(w[ed]);
                     field += ((st[q >> 5] >> (q & 31)) & 1u) ? j : -j;
                 }
                 const double si = ((st[p >> 5] >> (p & 31)) & 1u) ? 1.0 : -1.0;
-                e += si * (0.5 * field - (G.bias ? G.bias[p] : 0.0));
+                e += si * (0.5 * field - (L.bias ? L.bias[p] : 0.0));
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);

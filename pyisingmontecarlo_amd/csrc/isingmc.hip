@@ -76,6 +76,7 @@ struct isingmc_graph {
     uint32_t *d_fneg = nullptr; // fields of one size and both signs: sign planes [2][wpp] (bit set where h_i < 0); field = |h| then
     // general path
     GenGraphDev gdev{};
+    uint32_t gen_edges2 = 0; // directed edges of the CSR (rowptr[n_pos])
     bool w_is_float = false;
     std::vector<uint64_t> class_base;
     std::vector<uint64_t> pos; // site -> packed position
@@ -647,6 +648,7 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
     GenGraphDev &D = g->gdev;
     D.n_pos = n_pos;
     D.n_words = n_pos / 32;
+    g->gen_edges2 = uint32_t(nbr.size());
     TRY(graph_upload(g, &D.rowptr, rowptr));
     TRY(graph_upload(g, &D.nbr, nbr));
     TRY(graph_upload(g, &D.site, site));
@@ -2081,12 +2083,42 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
             unsigned threads = 64;
             for (uint32_t c = 0; c < g->n_colours; c++)
                 threads = std::max<unsigned>(threads, unsigned(std::min<uint64_t>(1024, g->class_base[c + 1] - g->class_base[c])));
+            // the graph in LDS too (gen_resident_kernel STAGE) while every replica of the call can still be resident at once (160 KB
+            // of LDS per compute unit): small graphs, where a timestep is a chain of dependent loads.  Everything when that fits,
+            // else the topology alone (the links of the chain); ISINGMC_GEN_STAGE=0 / 1 / 2 forces none / all / topology (A/B runs)
+            static const int stage_mode = env_int("ISINGMC_GEN_STAGE", -1);
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
+            const size_t lds_cu = 160 * 1024, lds_max = 150 * 1024; // (a few KB stay free for the kernel's static LDS)
+            size_t stage_bytes = 0;
+            int stage = 0;
+            {
+                size_t bytes[3] = {0, 0, 0}, resident[3] = {0, 0, 0};
+                for (int mode = 1; mode <= 2; mode++) {
+                    bytes[mode] = size_t(gen_stage_words(g->gdev.n_pos, g->gen_edges2, g->gdev.bias != nullptr, g->w_is_float ? 4 : 8, mode)) * 4;
+                    if (bytes[mode] <= lds_max) resident[mode] = std::min<size_t>(2048 / threads, lds_cu / (bytes[mode] + 1024)); // workgroups per compute unit
+                }
+                if (stage_mode == 0) stage = 0;
+                else if (stage_mode == 1 || stage_mode == 2) stage = resident[stage_mode] ? stage_mode : 0;
+                else if (resident[1] && (R <= size_t(n_cu) * resident[1] || threads > 512 || resident[2] <= resident[1])) stage = 1;
+                // (measured, tools/small_graph_stage_ab.py: workgroups of <= 512 threads gain from running side by side, so when
+                //  the full copy would keep some of the call's replicas waiting the smaller one wins: 32^2 x 1024 5.7 against
+                //  6.2 us, 8^3 x 1024 3.5 against 4.4; 1024-thread workgroups do not: 12^3 x 512 6.6 against 9.4)
+                else if (resident[2]) stage = 2;
+                stage_bytes = bytes[stage];
+            }
             const auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), g->state_words * sizeof(uint32_t), s->stream,
+                if (stage_bytes > 64 * 1024) // beyond the default limit of dynamic LDS
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(stage_bytes));
+                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), stage ? stage_bytes : g->state_words * sizeof(uint32_t), s->stream,
                                    s->d_state, g->gdev, s->t, uint32_t(nk), s->d_keys, d_beta_steps, uint32_t(beta_stride ? 1 : 0),
-                                   s->has_betas ? s->d_beta : nullptr, d_gen_energies, g->self_energy);
+                                   s->has_betas ? s->d_beta : nullptr, d_gen_energies, g->self_energy, g->gen_edges2);
             };
-            if (g->w_is_float) launch(gen_resident_kernel<float>); else launch(gen_resident_kernel<double>);
+            if (g->w_is_float) {
+                if (stage == 1) launch(gen_resident_kernel<float, 1>); else if (stage == 2) launch(gen_resident_kernel<float, 2>); else launch(gen_resident_kernel<float, 0>);
+            } else {
+                if (stage == 1) launch(gen_resident_kernel<double, 1>); else if (stage == 2) launch(gen_resident_kernel<double, 2>); else launch(gen_resident_kernel<double, 0>);
+            }
             s->t += nk;
             if (d_gen_energies) {
                 std::vector<double> he(nk * R);
