@@ -10,10 +10,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/isingmc.h"
@@ -55,6 +57,246 @@ static int fail(int code, const std::string &msg)
 // ------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Device blocks are recycled: a call of the reference's API creates its replicas, runs and drops them again
+// (Lattice.run_monte_carlo, lattice.rs:171-221), and for a small lattice hipMalloc / hipFree -- each a device-wide
+// synchronisation -- cost more than the timesteps: 2.1 ms of a 2.2 ms call of ONE timestep on 16 x 16 x 4 (tools/small_call_overhead.py).
+// Freed blocks of up to 64 MiB wait in a per-device list (at most 512 MiB / 256 blocks) for the next request of exactly their
+// size.  Every owner synchronises its streams before it frees (hipFree did that implicitly).  ISINGMC_NO_ALLOC_CACHE=1: off.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::unordered_map<void *, std::pair<int, size_t>> live;        // block -> (device, bytes)
+    std::multimap<std::pair<int, size_t>, void *> idle;             // (device, bytes) -> block
+    size_t idle_bytes = 0;
+    static constexpr size_t MAX_BLOCK = size_t(64) << 20, MAX_IDLE = size_t(512) << 20, MAX_COUNT = 256;
+};
+DevCache &dev_cache()
+{
+    static DevCache *c = new DevCache; // never destroyed: the HIP runtime may be gone by the time static destructors run
+    return *c;
+}
+bool dev_cache_off()
+{
+    static const bool off = [] { const char *e = std::getenv("ISINGMC_NO_ALLOC_CACHE"); return e && *e && *e != '0'; }();
+    return off;
+}
+} // namespace
+
+static hipError_t cached_malloc(void **out, size_t bytes)
+{
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    DevCache &c = dev_cache();
+    if (!dev_cache_off()) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.idle.find({dev, bytes});
+        if (it != c.idle.end()) {
+            *out = it->second;
+            c.idle.erase(it);
+            c.idle_bytes -= bytes;
+            c.live[*out] = {dev, bytes};
+            return hipSuccess;
+        }
+    }
+    err = hipMalloc(out, bytes);
+    if (err != hipSuccess && !dev_cache_off()) { // out of memory: give the idle blocks back and try once more
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(c.mu);
+            for (auto &kv : c.idle) drop.push_back(kv.second);
+            c.idle.clear();
+            c.idle_bytes = 0;
+        }
+        for (void *p : drop) (void)hipFree(p);
+        (void)hipGetLastError();
+        err = hipMalloc(out, bytes);
+    }
+    if (err == hipSuccess && !dev_cache_off()) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        c.live[*out] = {dev, bytes};
+    }
+    return err;
+}
+
+static hipError_t cached_free(void *p)
+{
+    if (!p) return hipSuccess;
+    DevCache &c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const auto key = it->second;
+            c.live.erase(it);
+            if (!dev_cache_off() && key.second <= DevCache::MAX_BLOCK && c.idle_bytes + key.second <= DevCache::MAX_IDLE &&
+                c.idle.size() < DevCache::MAX_COUNT) {
+                c.idle.emplace(key, p);
+                c.idle_bytes += key.second;
+                return hipSuccess;
+            }
+        }
+    }
+    return hipFree(p);
+}
+
+// ... and pinned host blocks (the staging buffers of get_states / the sampling pipeline: pinning and unpinning cost ~150 us each)
+namespace {
+struct HostCache {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;
+    std::multimap<size_t, void *> idle;
+    size_t idle_bytes = 0;
+};
+HostCache &host_cache()
+{
+    static HostCache *c = new HostCache;
+    return *c;
+}
+} // namespace
+
+static hipError_t cached_host_malloc(void **out, size_t bytes)
+{
+    HostCache &c = host_cache();
+    if (!dev_cache_off()) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.idle.find(bytes);
+        if (it != c.idle.end()) {
+            *out = it->second;
+            c.idle.erase(it);
+            c.idle_bytes -= bytes;
+            c.live[*out] = bytes;
+            return hipSuccess;
+        }
+    }
+    const hipError_t err = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (err == hipSuccess && !dev_cache_off()) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        c.live[*out] = bytes;
+    }
+    return err;
+}
+
+static hipError_t cached_host_free(void *p)
+{
+    if (!p) return hipSuccess;
+    HostCache &c = host_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t bytes = it->second;
+            c.live.erase(it);
+            if (!dev_cache_off() && bytes <= (size_t(64) << 20) && c.idle_bytes + bytes <= (size_t(256) << 20) && c.idle.size() < 64) {
+                c.idle.emplace(bytes, p);
+                c.idle_bytes += bytes;
+                return hipSuccess;
+            }
+        }
+    }
+    return hipHostFree(p);
+}
+
+// Streams are recycled the same way (creating and destroying the three streams of a replica container took ~1.5 ms of that
+// call): non-blocking streams per device, handed back idle (their owner synchronises them first).
+namespace {
+struct StreamPool {
+    std::mutex mu;
+    std::multimap<int, hipStream_t> idle; // device -> stream
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *p = new StreamPool;
+    return *p;
+}
+} // namespace
+
+static hipError_t pooled_stream_create(hipStream_t *out)
+{
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (!dev_cache_off()) {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto it = p.idle.find(dev);
+        if (it != p.idle.end()) {
+            *out = it->second;
+            p.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+// hipStreamSynchronize costs ~70 us even on an idle stream; a query is enough when everything has completed
+static hipError_t stream_quiesce(hipStream_t st)
+{
+    if (hipStreamQuery(st) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError(); // hipErrorNotReady is not an error
+    return hipStreamSynchronize(st);
+}
+
+static void pooled_stream_destroy(hipStream_t st)
+{
+    if (!st) return;
+    int dev = 0;
+    if (!dev_cache_off() && stream_quiesce(st) == hipSuccess && hipGetDevice(&dev) == hipSuccess) {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (p.idle.size() < 64) {
+            p.idle.emplace(dev, st);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(st);
+}
+
+// ... and events (two kinds: with timing for the *_timed entry point, without for ordering between streams)
+namespace {
+struct EventPool {
+    std::mutex mu;
+    std::vector<hipEvent_t> idle[2]; // [timing disabled?]
+};
+EventPool &event_pool()
+{
+    static EventPool *p = new EventPool;
+    return *p;
+}
+} // namespace
+
+static hipError_t pooled_event_create(hipEvent_t *out, bool disable_timing)
+{
+    if (!dev_cache_off()) {
+        EventPool &p = event_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto &v = p.idle[disable_timing ? 1 : 0];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return disable_timing ? hipEventCreateWithFlags(out, hipEventDisableTiming) : hipEventCreate(out);
+}
+
+static void pooled_event_destroy(hipEvent_t ev, bool disable_timing)
+{
+    if (!ev) return;
+    if (!dev_cache_off()) {
+        EventPool &p = event_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto &v = p.idle[disable_timing ? 1 : 0];
+        if (v.size() < 256) {
+            v.push_back(ev);
+            return;
+        }
+    }
+    (void)hipEventDestroy(ev);
+}
+
 struct isingmc_graph {
     int device = 0;
     int kind = ISINGMC_KIND_GENERAL;
@@ -101,7 +343,8 @@ struct isingmc_graph {
     ~isingmc_graph()
     {
         (void)hipSetDevice(device);
-        for (void *p : dev_allocs) (void)hipFree(p);
+        (void)hipDeviceSynchronize(); // the blocks are recycled (cached_free): no kernel may still be reading the graph
+        for (void *p : dev_allocs) (void)cached_free(p);
     }
 };
 
@@ -172,38 +415,43 @@ struct isingmc_states {
     {
         if (!g) return;
         (void)hipSetDevice(g->device);
+        // the blocks below go back to the cache, where the next request may pick them up at once: nothing of this object may
+        // still be running (hipFree used to wait for the whole device)
+        if (stream) (void)stream_quiesce(stream);
+        for (auto st : lanes) (void)stream_quiesce(st);
+        if (copy_stream) (void)stream_quiesce(copy_stream);
         for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
-            if (p) (void)hipFree(p);
-        if (d_tab) (void)hipFree(d_tab);
-        if (d_rj_betas) (void)hipFree(d_rj_betas);
-        if (d_pk_slot_thr) (void)hipFree(d_pk_slot_thr);
-        if (d_thr_mc) (void)hipFree(d_thr_mc);
+            if (p) (void)cached_free(p);
+        if (d_tab) (void)cached_free(d_tab);
+        if (d_rj_betas) (void)cached_free(d_rj_betas);
+        if (d_pk_slot_thr) (void)cached_free(d_pk_slot_thr);
+        if (d_thr_mc) (void)cached_free(d_thr_mc);
         for (int b = 0; b < 2; b++) {
             for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
-                if (p) (void)hipFree(p);
+                if (p) (void)cached_free(p);
             for (void *p : {(void *)h_samples[b], (void *)h_counts[b], (void *)h_e[b]})
-                if (p) (void)hipHostFree(p);
-            if (sample_ready[b]) (void)hipEventDestroy(sample_ready[b]);
-            if (sample_copied[b]) (void)hipEventDestroy(sample_copied[b]);
+                if (p) (void)cached_host_free(p);
+            pooled_event_destroy(sample_ready[b], true);
+            pooled_event_destroy(sample_copied[b], true);
         }
-        if (d_sample_m) (void)hipFree(d_sample_m);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (d_halo) (void)hipFree(d_halo);
-        if (d_strip_err) (void)hipFree(d_strip_err);
-        if (d_strip_fin) (void)hipFree(d_strip_fin);
-        if (d_snapshot) (void)hipFree(d_snapshot);
+        if (d_sample_m) (void)cached_free(d_sample_m);
+        pooled_stream_destroy(copy_stream);
+        if (d_halo) (void)cached_free(d_halo);
+        if (d_strip_err) (void)cached_free(d_strip_err);
+        if (d_strip_fin) (void)cached_free(d_strip_fin);
+        if (d_snapshot) (void)cached_free(d_snapshot);
         for (void *p : {(void *)d_pt_mail, (void *)d_pt_round_counts, (void *)d_pt_perm2})
-            if (p) (void)hipFree(p);
+            if (p) (void)cached_free(p);
         for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
                         (void *)d_pt_counters})
-            if (p) (void)hipFree(p);
-        for (auto st : lanes) (void)hipStreamDestroy(st);
-        for (auto ev : lane_events) (void)hipEventDestroy(ev);
-        if (fork_event) (void)hipEventDestroy(fork_event);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+            if (p) (void)cached_free(p);
+        for (auto st : lanes) pooled_stream_destroy(st);
+        for (auto ev : lane_events) pooled_event_destroy(ev, true);
+        pooled_event_destroy(fork_event, true);
+        pooled_event_destroy(ev0, false);
+        pooled_event_destroy(ev1, false);
+        pooled_stream_destroy(stream);
     }
 };
 
@@ -211,7 +459,7 @@ template <typename T>
 static int dev_alloc(T **out, size_t count)
 {
     *out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(cached_malloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T)));
     return ISINGMC_OK;
 }
 
@@ -225,7 +473,7 @@ struct DeviceScratch {
     {
         if (ptrs.empty()) return;
         (void)hipStreamSynchronize(stream);
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs) (void)cached_free(p);
     }
     template <typename T>
     int alloc(T **out, size_t count)
@@ -921,7 +1169,7 @@ static int reserve(isingmc_states *s, size_t cap)
         uint32_t **a;
         uint2 **b;
         bool armed = true;
-        ~Undo() { if (armed) { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); } }
+        ~Undo() { if (armed) { if (*a) (void)cached_free(*a); if (*b) (void)cached_free(*b); } }
     } undo{&d_state, &d_keys};
     TRY(dev_alloc(&d_state, cap * g->state_words));
     TRY(dev_alloc(&d_keys, cap));
@@ -932,7 +1180,7 @@ static int reserve(isingmc_states *s, size_t cap)
     undo.armed = false;
     for (void *p : {(void *)s->d_state, (void *)s->d_keys, (void *)s->d_thr, (void *)s->d_beta, (void *)s->d_meas,
                     (void *)s->d_pe, (void *)s->d_oe, (void *)s->d_pm, (void *)s->d_om})
-        if (p) (void)hipFree(p);
+        if (p) (void)cached_free(p);
     s->d_state = d_state;
     s->d_keys = d_keys;
     s->d_thr = nullptr; s->d_beta = nullptr; s->d_meas = nullptr;
@@ -984,9 +1232,9 @@ extern "C" int isingmc_states_create_range(isingmc_graph *g, size_t n_total, con
     TRY(use_device(g->device));
     auto s = std::make_unique<isingmc_states>();
     s->g = g;
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&s->ev0));
-    HIP_TRY(hipEventCreate(&s->ev1));
+    HIP_TRY(pooled_stream_create(&s->stream));
+    HIP_TRY(pooled_event_create(&s->ev0, false));
+    HIP_TRY(pooled_event_create(&s->ev1, false));
     TRY(lanes_reserve(s.get(), 2)); // created up front: the first multi-lane run must not pay for stream creation
     s->n_total = n_total;
     s->first = first;
@@ -1078,7 +1326,7 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
     if (s->g->kind == ISINGMC_KIND_LATTICE2D && s->g->mc_mode != MC_NONE) {
         std::vector<LatThrMC> thr(s->R);
         for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds_mc(s->g, s->betas[r]);
-        if (s->d_thr_mc) HIP_TRY(hipFree(s->d_thr_mc));
+        if (s->d_thr_mc) HIP_TRY(cached_free(s->d_thr_mc));
         s->d_thr_mc = nullptr;
         TRY(dev_alloc(&s->d_thr_mc, s->cap));
         if (s->R) HIP_TRY(hipMemcpyAsync(s->d_thr_mc, thr.data(), s->R * sizeof(LatThrMC), hipMemcpyHostToDevice, s->stream));
@@ -1221,7 +1469,7 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
         uint2 *d_keys = nullptr;
         unsigned long long *d_meas = nullptr;
         TRY(dev_alloc(&d_state, groups * g->pk.n_pos));
-        struct Undo { void *a, **b, **c; bool armed = true; ~Undo() { if (armed) { (void)hipFree(a); if (*b) (void)hipFree(*b); if (*c) (void)hipFree(*c); } } }
+        struct Undo { void *a, **b, **c; bool armed = true; ~Undo() { if (armed) { (void)cached_free(a); if (*b) (void)cached_free(*b); if (*c) (void)cached_free(*c); } } }
             undo{d_state, reinterpret_cast<void **>(&d_keys), reinterpret_cast<void **>(&d_meas)};
         TRY(dev_alloc(&d_keys, groups));
         TRY(dev_alloc(&d_meas, 2 * 32 * groups));
@@ -1231,11 +1479,11 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
         const uint2 key = make_uint2(uint32_t(seed), uint32_t(seed >> 32));
         HIP_TRY(hipMemcpy(d_keys + s->groups, &key, sizeof key, hipMemcpyHostToDevice));
         undo.armed = false;
-        (void)hipFree(s->d_state); (void)hipFree(s->d_keys); (void)hipFree(s->d_meas);
+        (void)cached_free(s->d_state); (void)cached_free(s->d_keys); (void)cached_free(s->d_meas);
         s->d_state = d_state; s->d_keys = d_keys; s->d_meas = d_meas;
         s->meas_zero = false;
-        if (s->d_tab) { (void)hipFree(s->d_tab); s->d_tab = nullptr; }             // per-group tables: rebuilt by the next set_betas
-        if (s->d_rj_betas) { (void)hipFree(s->d_rj_betas); s->d_rj_betas = nullptr; }
+        if (s->d_tab) { (void)cached_free(s->d_tab); s->d_tab = nullptr; }             // per-group tables: rebuilt by the next set_betas
+        if (s->d_rj_betas) { (void)cached_free(s->d_rj_betas); s->d_rj_betas = nullptr; }
         hipLaunchKernelGGL(pk_init_kernel, dim3((g->pk.n_pos + 255) / 256, 1), dim3(256), 0, s->stream, s->d_state, g->pk, s->d_keys,
                            uint32_t(s->groups));
         HIP_TRY(hipGetLastError());
@@ -1561,12 +1809,12 @@ static int lanes_reserve(isingmc_states *s, size_t n)
     while (s->lanes.size() < n) {
         hipStream_t st;
         hipEvent_t ev;
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(pooled_stream_create(&st));
+        HIP_TRY(pooled_event_create(&ev, true));
         s->lanes.push_back(st);
         s->lane_events.push_back(ev);
     }
-    if (!s->fork_event) HIP_TRY(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+    if (!s->fork_event) HIP_TRY(pooled_event_create(&s->fork_event, true));
     return ISINGMC_OK;
 }
 
@@ -1810,7 +2058,7 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
     const isingmc_graph *g = s->g;
     const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
     if (s->halo_cap < granules) {
-        if (s->d_halo) HIP_TRY(hipFree(s->d_halo));
+        if (s->d_halo) HIP_TRY(cached_free(s->d_halo));
         s->d_halo = nullptr;
         s->halo_cap = 0;
         TRY(dev_alloc(&s->d_halo, granules));
@@ -1900,7 +2148,7 @@ static int snapshot_take(isingmc_states *s)
 {
     const size_t words = s->R * s->g->state_words;
     if (s->snapshot_cap < words) {
-        if (s->d_snapshot) HIP_TRY(hipFree(s->d_snapshot));
+        if (s->d_snapshot) HIP_TRY(cached_free(s->d_snapshot));
         s->d_snapshot = nullptr;
         s->snapshot_cap = 0;
         TRY(dev_alloc(&s->d_snapshot, words));
@@ -2359,21 +2607,21 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
 template <typename T>
 static int regrow(T **dev, T **host, size_t count)
 {
-    if (*dev) HIP_TRY(hipFree(*dev));
-    if (*host) HIP_TRY(hipHostFree(*host));
+    if (*dev) HIP_TRY(cached_free(*dev));
+    if (*host) HIP_TRY(cached_host_free(*host));
     *dev = nullptr;
     *host = nullptr;
     TRY(dev_alloc(dev, count));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(host), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    HIP_TRY(cached_host_malloc(reinterpret_cast<void **>(host), std::max<size_t>(count, 1) * sizeof(T)));
     return ISINGMC_OK;
 }
 
 static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies)
 {
-    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    if (!s->copy_stream) HIP_TRY(pooled_stream_create(&s->copy_stream));
     for (int b = 0; b < 2; b++) {
-        if (!s->sample_ready[b]) HIP_TRY(hipEventCreateWithFlags(&s->sample_ready[b], hipEventDisableTiming));
-        if (!s->sample_copied[b]) HIP_TRY(hipEventCreateWithFlags(&s->sample_copied[b], hipEventDisableTiming));
+        if (!s->sample_ready[b]) HIP_TRY(pooled_event_create(&s->sample_ready[b], true));
+        if (!s->sample_copied[b]) HIP_TRY(pooled_event_create(&s->sample_copied[b], true));
     }
     HIP_TRY(hipStreamSynchronize(s->copy_stream));
     if (words > s->sample_cap_words) {
@@ -2389,7 +2637,7 @@ static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size
     if (energies > s->sample_cap_e) {
         s->sample_cap_e = 0;
         for (int b = 0; b < 2; b++) TRY(regrow(&s->d_sample_e[b], &s->h_e[b], energies));
-        if (s->d_sample_m) HIP_TRY(hipFree(s->d_sample_m));
+        if (s->d_sample_m) HIP_TRY(cached_free(s->d_sample_m));
         s->d_sample_m = nullptr;
         TRY(dev_alloc(&s->d_sample_m, energies));
         s->sample_cap_e = energies;
