@@ -258,7 +258,7 @@ static void pooled_stream_destroy(hipStream_t st)
 namespace {
 struct EventPool {
     std::mutex mu;
-    std::vector<hipEvent_t> idle[2]; // [timing disabled?]
+    std::multimap<std::pair<int, bool>, hipEvent_t> idle; // (device, timing disabled?) -> event
 };
 EventPool &event_pool()
 {
@@ -269,28 +269,30 @@ EventPool &event_pool()
 
 static hipError_t pooled_event_create(hipEvent_t *out, bool disable_timing)
 {
-    if (!dev_cache_off()) {
+    int dev = 0;
+    if (!dev_cache_off() && hipGetDevice(&dev) == hipSuccess) {
         EventPool &p = event_pool();
         std::lock_guard<std::mutex> lock(p.mu);
-        auto &v = p.idle[disable_timing ? 1 : 0];
-        if (!v.empty()) {
-            *out = v.back();
-            v.pop_back();
+        auto it = p.idle.find({dev, disable_timing});
+        if (it != p.idle.end()) {
+            *out = it->second;
+            p.idle.erase(it);
             return hipSuccess;
         }
     }
     return disable_timing ? hipEventCreateWithFlags(out, hipEventDisableTiming) : hipEventCreate(out);
 }
 
+// (called with the owner's device current, as the destructors and creators here are)
 static void pooled_event_destroy(hipEvent_t ev, bool disable_timing)
 {
     if (!ev) return;
-    if (!dev_cache_off()) {
+    int dev = 0;
+    if (!dev_cache_off() && hipGetDevice(&dev) == hipSuccess) {
         EventPool &p = event_pool();
         std::lock_guard<std::mutex> lock(p.mu);
-        auto &v = p.idle[disable_timing ? 1 : 0];
-        if (v.size() < 256) {
-            v.push_back(ev);
+        if (p.idle.size() < 256) {
+            p.idle.emplace(std::make_pair(dev, disable_timing), ev);
             return;
         }
     }
