@@ -2276,13 +2276,34 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
                 for (size_t k = 0; k < h_thr.size(); k++) h_thr[k] = lattice_thresholds(betas[(k0 + k) * beta_stride], g->jabs);
                 HIP_TRY(hipMemcpyAsync(d_thr_steps, h_thr.data(), h_thr.size() * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
             }
-            const unsigned threads = unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            // up to 128 quads per colour (64 x 64 ... 256 x 128): eight lanes per quad, one Philox call each (lat_resident_spread_kernel)
+            // ... while every replica of the call is resident at once: beyond that the one-lane-per-quad kernel's small workgroups fill
+            // the chip better (measured, tools/small_lattice_spread_ab.py: 64^2 x 2048 4.1 against 5.9 us, x 4096 10.5 against 9.1;
+            // 128^2 x 512 4.4 against 5.4, x 1024 8.7 against 5.3).  ISINGMC_RESIDENT_SPREAD=0 / 2: never / whenever the lattice allows
+            static const int spread_mode = env_int("ISINGMC_RESIDENT_SPREAD", 1);
+            bool spread = spread_mode != 0 && size_t(g->geom.nquads) * 8 <= 1024;
+            const unsigned spread_threads = unsigned((size_t(g->geom.nquads) * 8 + 63) / 64 * 64);
+            const size_t spread_lds = g->state_words * sizeof(uint32_t) + size_t(g->geom.nquads) * 8 * sizeof(uint4);
+            if (spread && spread_mode != 2) {
+                int per_cu = 0, n_cu = 256;
+                const void *fn = g->vec ? (g->uniform_sign ? (const void *)lat_resident_spread_kernel<true, false> : (const void *)lat_resident_spread_kernel<true, true>)
+                                        : (g->uniform_sign ? (const void *)lat_resident_spread_kernel<false, false> : (const void *)lat_resident_spread_kernel<false, true>);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, int(spread_threads), spread_lds) != hipSuccess) per_cu = 0;
+                (void)hipGetLastError();
+                (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
+                spread = per_cu > 0 && R <= size_t(n_cu) * size_t(per_cu);
+            }
+            const unsigned threads = spread ? spread_threads : unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            const size_t lds = spread ? spread_lds : g->state_words * sizeof(uint32_t);
             const auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), g->state_words * sizeof(uint32_t), s->stream,
+                hipLaunchKernelGGL(kernel, dim3(unsigned(R)), dim3(threads), lds, s->stream,
                                    s->d_state, g->geom, s->t, uint32_t(nk), s->d_keys, d_thr_steps, uint32_t(beta_stride ? 1 : 0),
                                    s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform, d_steps, uint32_t(R));
             };
-            if (g->vec) { if (g->uniform_sign) launch(lat_resident_kernel<true, false>); else launch(lat_resident_kernel<true, true>); }
+            if (spread) {
+                if (g->vec) { if (g->uniform_sign) launch(lat_resident_spread_kernel<true, false>); else launch(lat_resident_spread_kernel<true, true>); }
+                else { if (g->uniform_sign) launch(lat_resident_spread_kernel<false, false>); else launch(lat_resident_spread_kernel<false, true>); }
+            } else if (g->vec) { if (g->uniform_sign) launch(lat_resident_kernel<true, false>); else launch(lat_resident_kernel<true, true>); }
             else { if (g->uniform_sign) launch(lat_resident_kernel<false, false>); else launch(lat_resident_kernel<false, true>); }
             s->t += nk;
             if (k0 + nk < timesteps && !d_steps) HIP_TRY(hipStreamSynchronize(s->stream)); // h_thr is reused by the next chunk
