@@ -25,6 +25,7 @@
 #include "packed_kernels.hpp"
 #include "mc_types.hpp"
 #include "real_types.hpp"
+#include "spread_types.hpp"
 #include "strip_types.hpp"
 
 using namespace isingmc;
@@ -2285,11 +2286,8 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
             const unsigned spread_threads = unsigned((size_t(g->geom.nquads) * 8 + 63) / 64 * 64);
             const size_t spread_lds = g->state_words * sizeof(uint32_t) + size_t(g->geom.nquads) * 8 * sizeof(uint4);
             if (spread && spread_mode != 2) {
-                int per_cu = 0, n_cu = 256;
-                const void *fn = g->vec ? (g->uniform_sign ? (const void *)lat_resident_spread_kernel<true, false> : (const void *)lat_resident_spread_kernel<true, true>)
-                                        : (g->uniform_sign ? (const void *)lat_resident_spread_kernel<false, false> : (const void *)lat_resident_spread_kernel<false, true>);
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, int(spread_threads), spread_lds) != hipSuccess) per_cu = 0;
-                (void)hipGetLastError();
+                int n_cu = 256;
+                const int per_cu = spread_blocks_per_cu(g->vec, !g->uniform_sign, spread_threads, spread_lds);
                 (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
                 spread = per_cu > 0 && R <= size_t(n_cu) * size_t(per_cu);
             }
@@ -2301,8 +2299,9 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
                                    s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform, d_steps, uint32_t(R));
             };
             if (spread) {
-                if (g->vec) { if (g->uniform_sign) launch(lat_resident_spread_kernel<true, false>); else launch(lat_resident_spread_kernel<true, true>); }
-                else { if (g->uniform_sign) launch(lat_resident_spread_kernel<false, false>); else launch(lat_resident_spread_kernel<false, true>); }
+                HIP_TRY(spread_launch(g->vec, !g->uniform_sign, unsigned(R), threads, lds, s->stream, s->d_state, g->geom, s->t, uint32_t(nk), s->d_keys,
+                                      d_thr_steps, uint32_t(beta_stride ? 1 : 0), s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform,
+                                      d_steps, uint32_t(R)));
             } else if (g->vec) { if (g->uniform_sign) launch(lat_resident_kernel<true, false>); else launch(lat_resident_kernel<true, true>); }
             else { if (g->uniform_sign) launch(lat_resident_kernel<false, false>); else launch(lat_resident_kernel<false, true>); }
             s->t += nk;

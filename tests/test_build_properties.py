@@ -101,7 +101,7 @@ def test_no_vector_store_data_is_overwritten_right_behind_the_store(device_asm, 
     No kernel of any translation unit may write such a store's data registers within 8 instructions of it."""
     texts = {"isingmc.hip": device_asm}
     procs = []
-    for name in ("mc_kernels.hip", "strip_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip"):   # every other translation unit
+    for name in ("mc_kernels.hip", "strip_kernels.hip", "spread_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip"):   # every other translation unit
         out = tmp_path / (name + ".s")
         procs.append((name, out, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
                                                    "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", name)],
