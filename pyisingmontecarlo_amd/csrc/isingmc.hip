@@ -2277,17 +2277,21 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
                 for (size_t k = 0; k < h_thr.size(); k++) h_thr[k] = lattice_thresholds(betas[(k0 + k) * beta_stride], g->jabs);
                 HIP_TRY(hipMemcpyAsync(d_thr_steps, h_thr.data(), h_thr.size() * sizeof(LatThr), hipMemcpyHostToDevice, s->stream));
             }
-            // up to 128 quads per colour (64 x 64 ... 256 x 128): eight lanes per quad, one Philox call each (lat_resident_spread_kernel)
+            // small lattices: eight (four, two) lanes per quad, one (two, four) Philox calls each (lat_resident_spread_kernel)
             // ... while every replica of the call is resident at once: beyond that the one-lane-per-quad kernel's small workgroups fill
             // the chip better (measured, tools/small_lattice_spread_ab.py: 64^2 x 2048 4.1 against 5.9 us, x 4096 10.5 against 9.1;
             // 128^2 x 512 4.4 against 5.4, x 1024 8.7 against 5.3).  ISINGMC_RESIDENT_SPREAD=0 / 2: never / whenever the lattice allows
             static const int spread_mode = env_int("ISINGMC_RESIDENT_SPREAD", 1);
-            bool spread = spread_mode != 0 && size_t(g->geom.nquads) * 8 <= 1024;
-            const unsigned spread_threads = unsigned((size_t(g->geom.nquads) * 8 + 63) / 64 * 64);
+            // eight lanes per quad only: with four or two (256 / 512 quads per colour, 1024 threads) the barriers of a 16-wave workgroup
+            // cost more than the shorter chain saves (256^2 x 64: 5.7 against 5.1 us; ISINGMC_RESIDENT_LPQ=4 / 2 for A/B runs)
+            static const int lpq_forced = env_int("ISINGMC_RESIDENT_LPQ", 0);
+            const int lpq = lpq_forced == 4 || lpq_forced == 2 ? lpq_forced : 8;
+            bool spread = spread_mode != 0 && size_t(g->geom.nquads) * size_t(lpq) <= 1024;
+            const unsigned spread_threads = unsigned((size_t(g->geom.nquads) * size_t(lpq) + 63) / 64 * 64);
             const size_t spread_lds = g->state_words * sizeof(uint32_t) + size_t(g->geom.nquads) * 8 * sizeof(uint4);
             if (spread && spread_mode != 2) {
                 int n_cu = 256;
-                const int per_cu = spread_blocks_per_cu(g->vec, !g->uniform_sign, spread_threads, spread_lds);
+                const int per_cu = spread_blocks_per_cu(g->vec, !g->uniform_sign, lpq, spread_threads, spread_lds);
                 (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
                 spread = per_cu > 0 && R <= size_t(n_cu) * size_t(per_cu);
             }
@@ -2299,7 +2303,7 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
                                    s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform, d_steps, uint32_t(R));
             };
             if (spread) {
-                HIP_TRY(spread_launch(g->vec, !g->uniform_sign, unsigned(R), threads, lds, s->stream, s->d_state, g->geom, s->t, uint32_t(nk), s->d_keys,
+                HIP_TRY(spread_launch(g->vec, !g->uniform_sign, lpq, unsigned(R), threads, lds, s->stream, s->d_state, g->geom, s->t, uint32_t(nk), s->d_keys,
                                       d_thr_steps, uint32_t(beta_stride ? 1 : 0), s->has_betas ? s->d_thr : nullptr, g->d_jneg, g->jneg_uniform,
                                       d_steps, uint32_t(R)));
             } else if (g->vec) { if (g->uniform_sign) launch(lat_resident_kernel<true, false>); else launch(lat_resident_kernel<true, true>); }

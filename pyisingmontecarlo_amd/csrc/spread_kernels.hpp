@@ -13,7 +13,8 @@ namespace isingmc {
 // the first residual call) and leaves its four words in LDS; after a barrier thread q (the first nquads threads: whole waves) takes quad q's 32 words and decides
 // exactly as quad_flips_pre does from pre-drawn words.  Same counters, same decisions: bit-identical to that kernel.
 static_assert(N_PLANES == 7, "lat_resident_spread_kernel: eight lanes per quad = 7 bit planes + the first residual call");
-template <bool VEC, bool PMJ>
+// LPQ = lanes per quad: 8 (one call each), 4 or 2 (two / four calls each) -- whatever lets 1024 threads cover the colour
+template <bool VEC, bool PMJ, int LPQ>
 __global__ __launch_bounds__(1024) void lat_resident_spread_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint64_t t0, const uint32_t timesteps,
     const uint2 *__restrict__ keys, const LatThr *__restrict__ thr_steps, const uint32_t thr_stride,
@@ -29,14 +30,17 @@ __global__ __launch_bounds__(1024) void lat_resident_spread_kernel(
         reinterpret_cast<uint4 *>(planes)[i] = reinterpret_cast<const uint4 *>(mine)[i];
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
-    const uint32_t quad = tid >> 3, call = tid & 7u; // blockDim.x >= 8 * nquads (host)
+    const uint32_t quad = tid / LPQ, call = tid % LPQ; // blockDim.x >= LPQ * nquads (host)
     __syncthreads();
     for (uint32_t k = 0; k < timesteps; k++) {
         const LatThr thr = thr_replica ? thr_replica[r] : thr_steps[size_t(k) * thr_stride];
         const uint64_t t = t0 + k;
         for (uint32_t colour = 0; colour < 2; colour++) {
-            if (quad < g.nquads) // Q == the quad's index under the row-major mapping (thread_to_quad<false>)
-                s_rand[tid] = philox4x32_10(make_uint4(uint32_t(t), quad, DOM_LAT_SWEEP, ctr2(t, colour, call)), key, vk);
+            if (quad < g.nquads) { // Q == the quad's index under the row-major mapping (thread_to_quad<false>)
+#pragma unroll
+                for (uint32_t c = 0; c < 8 / LPQ; c++)
+                    s_rand[8 * quad + call + LPQ * c] = philox4x32_10(make_uint4(uint32_t(t), quad, DOM_LAT_SWEEP, ctr2(t, colour, call + LPQ * c)), key, vk);
+            }
             __syncthreads();
             if (tid < g.nquads) { // the deciding lanes are the FIRST nquads threads: whole waves, not every eighth lane of all of them
                 QuadRandom R;

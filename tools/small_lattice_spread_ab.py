@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from pyisingmontecarlo_amd import _capi  # noqa: E402
 from tools.bench_configs import square  # noqa: E402
 
-for (W, H), R, glass in (((64, 16), 4, False), ((64, 64), 4, False), ((64, 64), 64, False), ((64, 64), 64, True), ((128, 128), 64, False), ((256, 128), 64, False),
+for (W, H), R, glass in (((256, 256), 64, False), ((512, 256), 64, False), ((512, 512), 64, False), ((256, 256), 256, False), ((512, 512), 256, False), ((64, 16), 4, False), ((64, 64), 4, False), ((64, 64), 64, False), ((64, 64), 64, True), ((128, 128), 64, False), ((256, 128), 64, False),
                          ((256, 256), 64, False), ((64, 64), 4096, False), ((128, 128), 2048, False),
                          ((64, 64), 256, False), ((64, 64), 512, False), ((64, 64), 1024, False), ((64, 64), 2048, False), ((128, 128), 256, False), ((128, 128), 512, False), ((128, 128), 1024, False), ((256, 128), 256, False), ((256, 128), 512, False)):
     ea, eb, ej = square(W, H, np.random.default_rng(1) if glass else None)
