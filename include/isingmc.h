@@ -78,6 +78,10 @@ typedef struct {
 
 const char *isingmc_last_error(void);
 int isingmc_abi_version(void);
+/* The library recycles freed device blocks, pinned host blocks, streams and events between calls (a call of the reference's
+ * API creates and drops its replicas; for small lattices hipMalloc / hipFree cost more than the timesteps).  This hands everything
+ * that is idle back to the runtime; returns the number of bytes released.  (ISINGMC_NO_ALLOC_CACHE=1 disables the recycling.) */
+size_t isingmc_release_cached_resources(void);
 int isingmc_device_count(int *count);
 
 /* ---- host-only helpers (no device) ------------------------------------------------------ */

@@ -26,6 +26,7 @@ _vp = C.c_void_p
 _PROTOTYPES = {
     "isingmc_last_error": (C.c_char_p, []),
     "isingmc_abi_version": (C.c_int, []),
+    "isingmc_release_cached_resources": (C.c_size_t, []),
     "isingmc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "isingmc_host_make_seeds": (C.c_int, [C.c_int, C.c_uint64, C.c_size_t, _vp]),
     "isingmc_host_expand_schedule": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]),
@@ -205,6 +206,11 @@ def pt_swap_round(seed, rnd, betas, slot_energy, perm):
     _check(lib().isingmc_host_pt_swap_round(C.c_uint64(int(seed)), C.c_uint64(int(rnd)), len(betas), _p(betas),
                                             _p(slot_energy), _p(perm), C.byref(swaps)))
     return swaps.value
+
+
+def release_cached_resources():
+    """Hand the library's idle device blocks, pinned host blocks, streams and events back to the runtime; bytes released."""
+    return int(lib().isingmc_release_cached_resources())
 
 
 class Graph:

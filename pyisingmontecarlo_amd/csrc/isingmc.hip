@@ -631,6 +631,48 @@ extern "C" const char *isingmc_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int isingmc_abi_version(void) { return ISINGMC_ABI_VERSION; }
 
+extern "C" size_t isingmc_release_cached_resources(void)
+{
+    size_t bytes = 0;
+    std::vector<void *> dev_blocks, host_blocks;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+    {
+        DevCache &c = dev_cache();
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto &kv : c.idle) dev_blocks.push_back(kv.second);
+        bytes += c.idle_bytes;
+        c.idle.clear();
+        c.idle_bytes = 0;
+    }
+    {
+        HostCache &c = host_cache();
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto &kv : c.idle) host_blocks.push_back(kv.second);
+        bytes += c.idle_bytes;
+        c.idle.clear();
+        c.idle_bytes = 0;
+    }
+    {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (auto &kv : p.idle) streams.push_back(kv.second);
+        p.idle.clear();
+    }
+    {
+        EventPool &p = event_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (auto &kv : p.idle) events.push_back(kv.second);
+        p.idle.clear();
+    }
+    for (void *b : dev_blocks) (void)hipFree(b);
+    for (void *b : host_blocks) (void)hipHostFree(b);
+    for (hipStream_t st : streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+    (void)hipGetLastError();
+    return bytes;
+}
+
 extern "C" int isingmc_device_count(int *count)
 {
     if (!count) return fail(ISINGMC_ERR_INVALID, "count is NULL");

@@ -601,3 +601,20 @@ def test_bias_sign_compat_switch(mod, monkeypatch):
     lat2.set_global_bias(2.0)
     e2, s2 = lat2.run_monte_carlo(5.0, 50, 4)
     assert not s2.any() and np.array_equal(e2, e)
+
+
+def test_cached_resources_can_be_released(capi, exact):
+    """Freed device blocks, pinned buffers, streams and events wait for the next call (small calls are dominated by their
+    creation otherwise); isingmc_release_cached_resources hands them back, and the next call simply allocates again."""
+    ea, eb, ej = exact.square_lattice_edges(64, 16, -1.0)
+    g = capi.Graph(ea, eb, ej)
+    seeds = capi.make_seeds(3, 4)
+    st = capi.States(g, seeds)
+    st.do_time_steps(3, 0.4)
+    want_e, want_s = st.energies(), st.states()
+    del st
+    assert capi.release_cached_resources() > 0
+    assert capi.release_cached_resources() == 0
+    st = capi.States(g, seeds)
+    st.do_time_steps(3, 0.4)
+    assert np.array_equal(st.energies(), want_e) and np.array_equal(st.states(), want_s)
