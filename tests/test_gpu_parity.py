@@ -537,3 +537,29 @@ def test_looping_kernel_at_headline_width_bit_exact(capi, oracle, exact):
             lat.sweep(ref, seeds[r], t, beta)
         np.testing.assert_array_equal(packed[r], ref, err_msg=f"replica {r}")
         assert energies[r] == lat.energy_mag(ref)[0]
+
+
+@pytest.mark.parametrize("kind", ["everything staged", "topology staged", "nothing staged"])
+def test_resident_csr_kernel_with_the_graph_in_lds(capi, oracle, exact, kind):
+    """gen_resident_kernel keeps the graph in LDS when it fits (everything: 24 x 20; the topology alone: 64 x 64 with f64
+    couplings; nothing: 19^3) -- the same arithmetic in the same order, so all three equal oracle engine C bit for bit."""
+    rng = np.random.default_rng(19)
+    if kind == "everything staged":
+        ea, eb, _ = exact.square_lattice_edges(24, 20, 1.0)
+    elif kind == "topology staged":
+        ea, eb, _ = exact.square_lattice_edges(64, 64, 1.0)
+    else:
+        ea, eb, _ = exact.cubic_lattice_edges(19, 1.0)
+    n = int(max(ea.max(), eb.max())) + 1
+    ej = rng.normal(size=len(ea))
+    biases = rng.normal(size=n) * 0.3
+    g = capi.Graph(ea, eb, ej, nvars=n, biases=biases, force_general=True)
+    seeds = capi.make_seeds(23, 3)
+    st = capi.States(g, seeds)
+    betas = np.array([0.3, 0.7, 1.4])
+    eps = st.do_time_steps(3, betas, per_step_energies=True)
+    spins = st.states().astype(np.uint8)
+    for r in range(3):
+        e_ref, s_ref, eps_ref = oracle.gen_run(ea, eb, ej, n, seeds[r], betas, biases=biases, per_step=True)
+        assert np.array_equal(spins[r], s_ref), (kind, r)
+        np.testing.assert_allclose(eps[r], eps_ref, rtol=1e-12)
