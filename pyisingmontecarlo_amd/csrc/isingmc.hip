@@ -2380,10 +2380,19 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
                 if (rc != ISINGMC_OK) break;
                 HIP_TRY(hipMemcpy(d_thr_mc_steps, h.data(), h.size() * sizeof(LatThrMC), hipMemcpyHostToDevice));
             }
-            const unsigned threads = unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            // small lattices, few enough replicas to be resident at once: eight lanes per quad (lat_mc_resident_kernel SPREAD; the
+            // kernel takes the spread form when the launch's LDS holds the random words too).  ISINGMC_RESIDENT_SPREAD=0: off
+            static const int mc_spread_mode = env_int("ISINGMC_RESIDENT_SPREAD", 1);
+            int mc_n_cu = 256;
+            (void)hipDeviceGetAttribute(&mc_n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
+            const size_t spread_threads = (size_t(g->geom.nquads) * 8 + 63) / 64 * 64;
+            const bool mc_spread = mc_spread_mode != 0 && spread_threads <= 1024 &&
+                                   (mc_spread_mode == 2 || R <= size_t(mc_n_cu) * std::max<size_t>(1, 1024 / spread_threads));
+            const unsigned threads = mc_spread ? unsigned(spread_threads) : unsigned(std::min<size_t>(1024, (g->geom.nquads + 63) / 64 * 64));
+            const size_t mc_lds = g->state_words * sizeof(uint32_t) + (mc_spread ? size_t(g->geom.nquads) * 8 * sizeof(uint4) : 0);
             for (size_t r0 = 0; r0 < R && rc == ISINGMC_OK; r0 += 65535) {
                 const size_t n = std::min<size_t>(65535, R - r0);
-                const hipError_t err = mc_launch_resident(g->mc_mode, !g->uniform_sign, unsigned(n), threads, g->state_words * sizeof(uint32_t),
+                const hipError_t err = mc_launch_resident(g->mc_mode, !g->uniform_sign, unsigned(n), threads, mc_lds,
                                                           s->stream, s->d_state + r0 * g->state_words, g->geom, s->t, uint32_t(nk), s->d_keys + r0,
                                                           d_thr_mc_steps, uint32_t(beta_stride ? 1 : 0),
                                                           s->has_betas ? s->d_thr_mc + r0 : nullptr, g->d_jneg, g->jneg_uniform, g->open, g->d_fneg,

@@ -46,13 +46,17 @@ static void launch_resident_mode(bool pmj, unsigned n_replicas, unsigned threads
         hipLaunchKernelGGL(kernel, dim3(n_replicas), dim3(threads), lds_bytes, stream, state, g, t0, timesteps, keys, thr_steps, thr_stride,
                            thr_replica, jneg, jneg_uniform, open, fneg, steps_out, steps_replicas);
     };
+    // lds_bytes beyond the two planes: room for the spread variant's random words (128 bytes per quad)
+    const bool spread = lds_bytes > size_t(2) * g.wpp * sizeof(uint32_t);
     if constexpr (MODE == MC_FIELD || MODE == MC_FIELD_OPEN) {
         if (fneg) {
-            if (pmj) launch(lat_mc_resident_kernel<MODE, true, true>); else launch(lat_mc_resident_kernel<MODE, false, true>);
+            if (spread) { if (pmj) launch(lat_mc_resident_kernel<MODE, true, true, true>); else launch(lat_mc_resident_kernel<MODE, false, true, true>); }
+            else { if (pmj) launch(lat_mc_resident_kernel<MODE, true, true, false>); else launch(lat_mc_resident_kernel<MODE, false, true, false>); }
             return;
         }
     }
-    if (pmj) launch(lat_mc_resident_kernel<MODE, true, false>); else launch(lat_mc_resident_kernel<MODE, false, false>);
+    if (spread) { if (pmj) launch(lat_mc_resident_kernel<MODE, true, false, true>); else launch(lat_mc_resident_kernel<MODE, false, false, true>); }
+    else { if (pmj) launch(lat_mc_resident_kernel<MODE, true, false, false>); else launch(lat_mc_resident_kernel<MODE, false, false, false>); }
 }
 
 hipError_t mc_launch_resident(int mode, bool pmj, unsigned n_replicas, unsigned threads, size_t lds_bytes, hipStream_t stream,

@@ -125,13 +125,26 @@ __global__ __launch_bounds__(256) void lat_mc_sweep_kernel(
     }
     const uint2 key = keys[r];
     const PhiloxVKeys vk = philox_vkeys(key);
+#define MC_RND(call) philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, (call))), key, vk)
 #include "mc_quad_body.inc"
+#undef MC_RND
+}
+
+static_assert(N_PLANES == 7, "SPREAD: eight lanes per quad = 7 bit planes + the first residual call");
+template <bool SPREAD>
+__device__ __forceinline__ uint4 mc_rnd(const uint32_t *s_rand_words, const uint32_t gid, const uint32_t call, const uint32_t c0,
+                                        const uint32_t Q, const uint64_t t, const uint32_t colour, const uint2 key, const PhiloxVKeys &vk)
+{
+    if constexpr (SPREAD) return reinterpret_cast<const uint4 *>(s_rand_words)[8 * gid + call];
+    else return philox4x32_10(make_uint4(c0, Q, DOM_LAT_SWEEP, ctr2(t, colour, call)), key, vk);
 }
 
 // LDS-resident variant for small lattices (both planes <= LDS_RESIDENT_MAX_BYTES): one workgroup owns one replica for
 // `timesteps` whole timesteps, with a workgroup barrier between the colours -- instead of two launches per timestep
 // (lat_resident_kernel's scheme for the multi-class modes).  Same quads, same counters: the same configurations.
-template <int MODE, bool PMJ, bool FS>
+// SPREAD (lattices of <= 128 quads per colour): eight lanes per quad draw its 7 + 1 Philox calls side by side into LDS, the
+// first nquads threads then decide their quads from those words -- as lat_resident_spread_kernel (spread_kernels.hpp)
+template <int MODE, bool PMJ, bool FS, bool SPREAD>
 __global__ __launch_bounds__(1024) void lat_mc_resident_kernel(
     uint32_t *__restrict__ state, const LatGeom g, const uint64_t t0, const uint32_t timesteps, const uint2 *__restrict__ keys,
     const LatThrMC *__restrict__ thr_steps, const uint32_t thr_stride, const LatThrMC *__restrict__ thr_replica,
@@ -160,8 +173,16 @@ __global__ __launch_bounds__(1024) void lat_mc_resident_kernel(
         const uint64_t t = t0 + k;
         for (uint32_t colour = 0; colour < 2; colour++) {
             const PtrPlanes mem{mc_planes + colour * g.wpp, mc_planes + (1 - colour) * g.wpp};
+            if constexpr (SPREAD) { // blockDim.x >= 8 * nquads (host); Q == gid under the row-major mapping
+                uint4 *s_rand = reinterpret_cast<uint4 *>(mc_planes + 2 * g.wpp);
+                if ((tid >> 3) < g.nquads)
+                    s_rand[tid] = philox4x32_10(make_uint4(uint32_t(t), tid >> 3, DOM_LAT_SWEEP, ctr2(t, colour, tid & 7u)), key, vk);
+                __syncthreads();
+            }
             for (uint32_t gid = tid; gid < g.nquads; gid += nthreads) {
+#define MC_RND(call) mc_rnd<SPREAD>(mc_planes + 2 * g.wpp, gid, (call), c0, Q, t, colour, key, vk)
 #include "mc_quad_body.inc"
+#undef MC_RND
             }
             __syncthreads();
         }
