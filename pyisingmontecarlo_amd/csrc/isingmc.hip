@@ -1221,6 +1221,7 @@ static int reserve(isingmc_states *s, size_t cap)
     if (s->R) {
         HIP_TRY(hipMemcpy(d_state, s->d_state, s->R * g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->R * sizeof(uint2), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipDeviceSynchronize()); // device-to-device copies may still run when hipMemcpy returns; the old blocks are recycled below
     }
     undo.armed = false;
     for (void *p : {(void *)s->d_state, (void *)s->d_keys, (void *)s->d_thr, (void *)s->d_beta, (void *)s->d_meas,
@@ -1371,6 +1372,7 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
     if (s->g->kind == ISINGMC_KIND_LATTICE2D && s->g->mc_mode != MC_NONE) {
         std::vector<LatThrMC> thr(s->R);
         for (size_t r = 0; r < s->R; r++) thr[r] = lattice_thresholds_mc(s->g, s->betas[r]);
+        HIP_TRY(stream_quiesce(s->stream)); // the old table may still be read by enqueued timesteps; its block is recycled
         if (s->d_thr_mc) HIP_TRY(cached_free(s->d_thr_mc));
         s->d_thr_mc = nullptr;
         TRY(dev_alloc(&s->d_thr_mc, s->cap));
@@ -1521,6 +1523,7 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
         HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemcpy(d_state, s->d_state, s->groups * g->pk.n_pos * sizeof(uint32_t), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->groups * sizeof(uint2), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipDeviceSynchronize()); // as in reserve(): the old blocks go back to the cache below
         const uint2 key = make_uint2(uint32_t(seed), uint32_t(seed >> 32));
         HIP_TRY(hipMemcpy(d_keys + s->groups, &key, sizeof key, hipMemcpyHostToDevice));
         undo.armed = false;
@@ -2103,6 +2106,7 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
     const isingmc_graph *g = s->g;
     const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
     if (s->halo_cap < granules) {
+        HIP_TRY(stream_quiesce(s->stream)); // recycled blocks: nothing enqueued may still use the old one
         if (s->d_halo) HIP_TRY(cached_free(s->d_halo));
         s->d_halo = nullptr;
         s->halo_cap = 0;
@@ -2193,6 +2197,7 @@ static int snapshot_take(isingmc_states *s)
 {
     const size_t words = s->R * s->g->state_words;
     if (s->snapshot_cap < words) {
+        HIP_TRY(stream_quiesce(s->stream));
         if (s->d_snapshot) HIP_TRY(cached_free(s->d_snapshot));
         s->d_snapshot = nullptr;
         s->snapshot_cap = 0;
@@ -2696,6 +2701,8 @@ static int regrow(T **dev, T **host, size_t count)
 static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies)
 {
     if (!s->copy_stream) HIP_TRY(pooled_stream_create(&s->copy_stream));
+    HIP_TRY(stream_quiesce(s->stream)); // buffers regrown below go through the block caches
+    HIP_TRY(stream_quiesce(s->copy_stream));
     for (int b = 0; b < 2; b++) {
         if (!s->sample_ready[b]) HIP_TRY(pooled_event_create(&s->sample_ready[b], true));
         if (!s->sample_copied[b]) HIP_TRY(pooled_event_create(&s->sample_copied[b], true));
