@@ -581,9 +581,11 @@ static double lattice_energy(const isingmc_graph *g, unsigned long long sat, uns
 }
 
 template <typename F>
-static void parallel_for(size_t n, F &&body)
+static void parallel_for(size_t n, F &&body, size_t bytes_per_item = size_t(1) << 20)
 {
-    const size_t nthreads = std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+    // small jobs run on the calling thread: starting and joining threads costs ~100 us, more than expanding a few KB
+    const size_t nthreads = n * bytes_per_item < (size_t(1) << 18)
+                                ? 1 : std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
     if (nthreads <= 1) {
         for (size_t i = 0; i < n; i++) body(i);
         return;
@@ -2609,7 +2611,7 @@ extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t
         if (j + 1 < n_slabs) TRY(copy_slab(j + 1)); // into the other buffer, which slab j-1's expansion has released
         const size_t r0 = j * slab, n = std::min(slab, s->R - r0);
         const uint32_t *words = s->h_samples[j & 1];
-        parallel_for(n, [&](size_t i) { unpack_state(g, words + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes); });
+        parallel_for(n, [&](size_t i) { unpack_state(g, words + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes); }, g->nvars);
     }
     return ISINGMC_OK;
 }
@@ -2821,7 +2823,7 @@ static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalizati
                 else energy = h_e[k * R + r] + g->self_energy;
             }
             energies_out[r * S + k0 + k] = energy;
-        });
+        }, N);
     };
     for (size_t j = 0; j < n_slabs; j++) {
         const size_t k0 = j * slab, nk = std::min(slab, S - k0), b = j & 1;
