@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ISINGMC_ABI_VERSION 3
+#define ISINGMC_ABI_VERSION 4
 
 enum {
     ISINGMC_OK = 0,
@@ -44,6 +44,11 @@ enum {
 
 /* isingmc_graph_create flags */
 #define ISINGMC_FLAG_FORCE_GENERAL 1u /* skip the lattice recogniser (BASELINE config c5) */
+/* Fix the kernel family from the GRAPH alone, never from the number of experiments: experiment k of a call then depends on
+ * seed k only (lattice.rs:83-91, 198), i.e. run_monte_carlo(beta, T, R)[k] is the same for every R > k.  Without the flag the
+ * faster family for the given R is chosen (small R on the f64 CSR kernels, large R replica-packed), and the two families are
+ * different Markov chains for the same Hamiltonian. */
+#define ISINGMC_FLAG_STABLE_PATH 2u
 
 typedef struct isingmc_graph isingmc_graph;   /* edges + biases: the per-experiment adjacency that
                                                  GraphState::new builds (lattice.rs:199), built once */
@@ -70,10 +75,15 @@ typedef struct {
     int32_t field_signs; /* LATTICE2D: 1 when the biases are +-field from site to site (sign planes), field = |h| then */
     int32_t packed_degree; /* GENERAL: d in 3..6 when the replica-packed path may use its one-degree kernel
                               (every site has d neighbours, every coupling the same size), else 0 */
-    int32_t real_slots;    /* GENERAL: 4, 7, 11 or 15 when the replica-packed REAL-COUPLING path applies (any f64 couplings,
+    int32_t real_slots;    /* GENERAL: 4, 7, 11, 15, 23 or 31 when the replica-packed REAL-COUPLING path applies (any f64 couplings,
                               lattice.rs:46-50, and any site biases, lattice.rs:104-131; degree <= real_slots), else 0 */
-    int32_t real_quantum_log2; /* that path computes with couplings rounded to multiples of 2^real_quantum_log2
-                              (2^-30 of the largest |h_i| + sum_e |J_e|); its energies are those of the rounded couplings */
+    int32_t real_quantum_log2; /* that path's DYNAMICS compute with couplings rounded to multiples of 2^real_quantum_log2
+                              (2^-30 of the largest |h_i| + sum_e |J_e|, never more than 2^-24 of the median term; heavy sites:
+                              2^-30 of their own |h_i| + sum_e |J_e|) */
+    int32_t real_energy_log2;  /* ... and its ENERGIES are those of the original couplings to within 2^(real_energy_log2 - 25)
+                              per term (two exact integer levels; = Fmax 2^-54) */
+    int32_t real_heavy_sites;  /* sites that quantise at a coarser scale of their own (pinned by a large bias, ...) */
+    int32_t stable_path;       /* 1 when created with ISINGMC_FLAG_STABLE_PATH */
 } isingmc_graph_info_t;
 
 const char *isingmc_last_error(void);
@@ -123,14 +133,23 @@ int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, co
 /* Host halves of the replica-packed REAL-COUPLING path -- what the device kernels are fed with, exposed
  * so that they can be checked without a GPU.  That path serves edge lists with couplings of several sizes
  * (lattice.rs:46-50 takes any f64) and arbitrary site biases (set_individual_bias / set_global_bias, lattice.rs:104-131)
- * on graphs of degree <= 15: couplings and biases become integers in units of 2^k, k = ilogb(Fmax) + 1 - 30,
- * Fmax = max_i (|h_i| + sum_e |J_e|).  jq_out: one value per input edge (0 for self-loops), hq_out: one per site;
- * *eligible_out: degree <= 15 and Fmax <= 64 x the median nonzero |coupling or bias| (else the f64 CSR path is used). */
+ * on graphs of degree <= 31.  Scales: F_i = |h_i| + sum_e |J_e|, Fmax = max_i F_i, med = the lower median nonzero
+ * |coupling or bias|; the graph's quantum is 2^k, k = ilogb(min(Fmax, 64 med)) + 1 - 30; site i quantises what it sees in units
+ * of 2^(k + d_i), d_i = max(0, ilogb(F_i) + 1 - 30 - k) capped at 31 (d_i > 0: a heavy site, e.g. one pinned by a large bias).
+ * jq_out: TWO values per input edge -- the bond as seen from edge_a[e] and from edge_b[e] (0, 0 for self-loops); hq_out and
+ * dshift_out: one per site; *eligible_out: degree <= 31, Fmax > 0 and every heavy site dominated by one term
+ * (4 max(|h_i|, max_e |J_e|) >= 3 F_i) -- else the f64 CSR path is used. */
 int isingmc_host_rj_quantise(const uint64_t *edge_a, const uint64_t *edge_b, const double *edge_j, size_t n_edges,
-                             size_t nvars, const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out,
-                             int *eligible_out);
-/* acceptance scale of one inverse temperature: a flip with half energy change X (units of 2^k) is accepted iff
- * max(X >> *shift_out, 0) <= (Lambda_q(u) * *mant_out) >> 32, Lambda_q(u) = 32 - log2(u) in Q24 for the 32-bit uniform u */
+                             size_t nvars, const double *biases, int32_t *jq_out, int32_t *hq_out, uint8_t *dshift_out,
+                             int *k_out, int *eligible_out);
+/* the energy of that path is the energy of the ORIGINAL couplings in two exact integer levels:
+ * x ~ hi 2^kE + lo 2^(kE - 24), kE = ilogb(Fmax) + 2 - 30, |x - (hi 2^kE + lo 2^(kE-24))| <= Fmax 2^-54;
+ * jhi_out / jlo_out per input edge (0 for self-loops), hhi_out / hlo_out per site */
+int isingmc_host_rj_energy_levels(const uint64_t *edge_a, const uint64_t *edge_b, const double *edge_j, size_t n_edges,
+                                  size_t nvars, const double *biases, int32_t *jhi_out, int32_t *jlo_out, int32_t *hhi_out,
+                                  int32_t *hlo_out, int *k_energy_out);
+/* acceptance scale of one inverse temperature: a flip of site i with half energy change X (units of 2^(k + d_i)) is accepted iff
+ * max(X >> (*shift_out - m), 0) <= ((Lambda_q(u) * *mant_out) >> 32) >> (d_i - m), m = min(*shift_out, d_i), Lambda_q(u) = 32 - log2(u) in Q24 for the 32-bit uniform u */
 int isingmc_host_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out);
 /* the 2049 entries of the log2(1 + i/2048) table behind Lambda_q (Q24, centred for linear interpolation) */
 int isingmc_host_rj_log_table(uint32_t *table_out);
@@ -223,6 +242,12 @@ int isingmc_run_sampling(isingmc_states *states, double beta, size_t thermalizat
  * ranks fewer); rung i starts on slot i; `seed` keys the exchange decisions. */
 int isingmc_pt_attach(isingmc_states *states, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
                       size_t slots_per_rank, size_t world_size, uint64_t seed);
+/* would isingmc_pt_attach accept this container and geometry?  *ok_out = 1 / 0, no side effects (when 0,
+ * isingmc_last_error() says why): the ranks of a sharded ladder agree on the answer BEFORE any of them attaches */
+int isingmc_pt_can_attach(const isingmc_states *states, size_t n_rungs, size_t slot_offset, size_t slots_per_rank,
+                          size_t world_size, int *ok_out);
+/* release the ladder (synchronises); configurations and timestep stay, the per-replica betas are cleared */
+int isingmc_pt_detach(isingmc_states *states);
 /* device pointers: local = double[slots_per_rank] (send buffer), all = double[world_size*slots_per_rank] */
 int isingmc_pt_buffers(isingmc_states *states, void **d_local_out, void **d_all_out, size_t *per_rank_out);
 int isingmc_pt_time_steps(isingmc_states *states, size_t timesteps); /* enqueue only */

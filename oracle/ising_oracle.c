@@ -861,28 +861,40 @@ void orc_pk_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
 /* ==========================================================================================
  * E. replica-packed REAL-COUPLING engine: any real J and any site biases
  * (lattice.rs:46-50 edge list, :104-131 set_individual_bias / set_global_bias, :186-189), graphs of
- * degree <= 15.  Same colouring, positions, replica groups, group keys and random start as engine D.
+ * degree <= 31.  Same colouring, positions, replica groups, group keys and random start as engine D.
  * The acceptance test runs in the LOG domain on integers, so that nothing per attempt needs exp():
  *
- *   quantisation (once per graph)   k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
- *                                   Jq_e = rint(J_e 2^-k), hq_i = rint(h_i 2^-k)   (int32, |X| <= ~2^30)
- *   half energy change              X = s_i (hq_i - sum_e Jq_e s_j)                (dE = 2 X 2^k)
+ *   scales (once per graph)         F_i = |h_i| + sum_e |J_e| (adjacency order), Fmax = max_i F_i, med = the lower median
+ *                                   of the nonzero |J_e| (every bond once) and |h_i|;
+ *                                   k0 = ilogb(min(Fmax, 64 med)) + 1 - 30      (the graph's quantum 2^k0)
+ *                                   k_i = max(k0, ilogb(F_i) + 1 - 30), d_i = min(k_i - k0, 31)   (a HEAVY site: d_i > 0)
+ *   quantisation AS SEEN FROM SITE i  Jq_e = rint(J_e 2^-k_i), hq_i = rint(h_i 2^-k_i)   (int32, |X_i| < 2^30 + 32)
+ *   half energy change              X_i = s_i (hq_i - sum_e Jq_e s_j)           (dE = 2 X_i 2^k_i)
  *   uniform                         u = word (b & 3) of Philox(key_g, (t_lo, p, "RJSW", ctr2(t,0,b>>2)))
  *                                   for replica bit b of the group at position p
  *   Lambda_q(u) ~ -log2(u / 2^32) in Q24 from the bits of (float)u: exponent field + a 2048-interval
  *                                   table of log2(1 + m) with linear interpolation
- *   per beta                        kappa = ln2 / (2 beta 2^k) (X units per unit of -log2 u);
+ *   per beta                        kappa = ln2 / (2 beta 2^k0) (quanta per unit of -log2 u);
  *                                   r = max(0, ilogb(kappa) - 23), mant = floor(kappa 2^(8 - r))
- *   accept                          iff max(X >> r, 0) <= (Lambda_q * mant) >> 32
- *                                   (u / 2^32 < exp(-beta dE) with ~2^-23 relative resolution in beta dE)
- *   energy                          E = 2^k (sum_bonds Jq s s - sum_i hq_i s_i) + sum of self-loop J
+ *   accept                          iff max(X_i >> (r - m), 0) <= ((Lambda_q * mant) >> 32) >> (d_i - m),  m = min(r, d_i)
+ *                                   (u / 2^32 < exp(-beta dE) with ~2^-23 relative resolution in beta dE; d_i = 0: m = 0)
+ *   eligible                        degree <= 31, Fmax > 0, and every heavy site is DOMINATED by one term:
+ *                                   4 max(|h_i|, max_e |J_e|) >= 3 F_i  (then |X_i| >= F_i / 2 whatever the spins: the coarser
+ *                                   quantum 2^k_i of a heavy site -- one pinning bias, one enormous bond -- cannot change a
+ *                                   decision that f64 arithmetic would take differently by more than 2^-29 of its exponent)
+ *   energy                          of the ORIGINAL couplings, two integer levels: kE = ilogb(Fmax) + 2 - 30,
+ *                                   hi = rint(x 2^-kE), lo = rint((x - hi 2^kE) 2^(24 - kE)) for every J_e (one value per bond)
+ *                                   and h_i;  E = 2^kE S(hi) + 2^(kE-24) S(lo) + sum of self-loop J,  S(q) = sum_bonds q s s -
+ *                                   sum_i q_i s_i as an exact int64 -- any summation order gives the same bits, and every
+ *                                   term is within Fmax 2^-54 of its f64 value
  *
  * Written spin by spin with a direct integer field sum: the HIP kernel's per-site tables, bit
  * transposition and carry tricks are checked against this independently.
  * ======================================================================================== */
 #define DOM_RJ_SWEEP 0x524A5357u /* "RJSW" */
-#define RJ_MAX_DEG 15
+#define RJ_MAX_DEG 31
 #define RJ_LOG_INTERVALS 2048
+#define RJ_LO_BITS 24
 
 /* LT[i] ~ log2(1 + x_i) 2^24, x_i = i / 2048, i = 0 .. 2048, centred for the interpolation that uses it: the chord of
  * the concave log2 lies below the curve by up to h^2 log2(e) / (8 (1 + x)^2) (h = 1/2048) and the interpolation rounds
@@ -911,60 +923,126 @@ uint32_t orc_rj_lambda(uint32_t u)
     return (159u << 24) - (E << 24) - val;
 }
 
-/* quantisation exponent k, quantised coupling per INPUT edge (0 for self-loops) and bias per site */
-void orc_rj_quantise(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
-                     const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out)
-{
-    adjacency A;
-    adj_build(&A, n_edges, ea, eb, ej, nvars);
-    double fmax = 0.0;
-    for (size_t i = 0; i < nvars; i++) {
-        double f = biases ? fabs(biases[i]) : 0.0;
-        for (size_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) f += fabs(A.w[e]);
-        if (f > fmax) fmax = f;
-    }
-    adj_free(&A);
-    int k = fmax > 0.0 ? ilogb(fmax) + 1 - 30 : 0;
-    if (k_out) *k_out = k;
-    for (size_t e = 0; e < n_edges && jq_out; e++)
-        jq_out[e] = ea[e] == eb[e] ? 0 : (int32_t)nearbyint(ldexp(ej[e], -k));
-    for (size_t i = 0; i < nvars && hq_out; i++)
-        hq_out[i] = biases ? (int32_t)nearbyint(ldexp(biases[i], -k)) : 0;
-}
+typedef struct {
+    double fmax, median;
+    size_t maxdeg;
+    int k0, kE;
+    int heavy;     /* some site has d_i > 0 */
+    int dominated; /* every heavy site is dominated by one term */
+    int *ksite;    /* k_i per site */
+} rj_scales;
 
-/* eligibility for this path: degree <= 15, Fmax > 0 and Fmax <= 64 x the (lower) median nonzero |coupling or bias|: the
- * absolute rounding error 2^(k-1) of a coupling is then below 2^-25 of that median */
 static int cmp_double(const void *a, const void *b)
 {
     double x = *(const double *)a, y = *(const double *)b;
     return (x > y) - (x < y);
 }
 
+static void rj_analyse(const adjacency *A, size_t nvars, const double *biases, rj_scales *S)
+{
+    size_t nnz = A->ptr[nvars], terms = 0;
+    double *mags = malloc((nnz / 2 + nvars + 1) * sizeof(double)), *F = malloc((nvars ? nvars : 1) * sizeof(double));
+    S->fmax = 0.0;
+    S->maxdeg = 0;
+    for (size_t i = 0; i < nvars; i++) {
+        double f = biases ? fabs(biases[i]) : 0.0;
+        if (f != 0.0) mags[terms++] = f;
+        for (size_t e = A->ptr[i]; e < A->ptr[i + 1]; e++) {
+            f += fabs(A->w[e]);
+            if (A->nbr[e] > i && A->w[e] != 0.0) mags[terms++] = fabs(A->w[e]); /* every bond once, from its lower end */
+        }
+        F[i] = f;
+        if (f > S->fmax) S->fmax = f;
+        if (A->ptr[i + 1] - A->ptr[i] > S->maxdeg) S->maxdeg = A->ptr[i + 1] - A->ptr[i];
+    }
+    S->median = 0.0;
+    if (terms) {
+        qsort(mags, terms, sizeof(double), cmp_double);
+        S->median = mags[(terms - 1) / 2];
+    }
+    free(mags);
+    double fbase = S->fmax < 64.0 * S->median ? S->fmax : 64.0 * S->median;
+    S->k0 = fbase > 0.0 ? ilogb(fbase) + 1 - 30 : 0;
+    S->kE = S->fmax > 0.0 ? ilogb(S->fmax) + 2 - 30 : 0;
+    S->ksite = malloc((nvars ? nvars : 1) * sizeof(int));
+    S->heavy = 0;
+    S->dominated = 1;
+    for (size_t i = 0; i < nvars; i++) {
+        int ki = F[i] > 0.0 ? ilogb(F[i]) + 1 - 30 : S->k0;
+        if (ki < S->k0) ki = S->k0;
+        S->ksite[i] = ki;
+        if (ki > S->k0) {
+            S->heavy = 1;
+            double m = biases ? fabs(biases[i]) : 0.0;
+            for (size_t e = A->ptr[i]; e < A->ptr[i + 1]; e++)
+                if (fabs(A->w[e]) > m) m = fabs(A->w[e]);
+            if (!(4.0 * m >= 3.0 * F[i])) S->dominated = 0;
+        }
+    }
+    free(F);
+}
+
+/* Quantisation for the dynamics: k0; per INPUT edge e the coupling as seen from its two ends, jq_out[2e] (from ea[e]) and
+ * jq_out[2e+1] (from eb[e]) (0, 0 for self-loops); per site the bias hq_out[i] and the shift d_i dshift_out[i] */
+void orc_rj_quantise(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                     const double *biases, int32_t *jq_out, int32_t *hq_out, uint8_t *dshift_out, int *k_out)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+    rj_scales S;
+    rj_analyse(&A, nvars, biases, &S);
+    adj_free(&A);
+    if (k_out) *k_out = S.k0;
+    for (size_t e = 0; e < n_edges && jq_out; e++) {
+        jq_out[2 * e] = ea[e] == eb[e] ? 0 : (int32_t)nearbyint(ldexp(ej[e], -S.ksite[ea[e]]));
+        jq_out[2 * e + 1] = ea[e] == eb[e] ? 0 : (int32_t)nearbyint(ldexp(ej[e], -S.ksite[eb[e]]));
+    }
+    for (size_t i = 0; i < nvars; i++) {
+        if (hq_out) hq_out[i] = biases ? (int32_t)nearbyint(ldexp(biases[i], -S.ksite[i])) : 0;
+        if (dshift_out) dshift_out[i] = (uint8_t)(S.ksite[i] - S.k0 > 31 ? 31 : S.ksite[i] - S.k0);
+    }
+    free(S.ksite);
+}
+
+/* the two integer levels of the energy: per INPUT edge (0 for self-loops) and per site */
+static void rj_two_levels(double x, int kE, int32_t *hi, int32_t *lo)
+{
+    double h = nearbyint(ldexp(x, -kE));
+    *hi = (int32_t)h;
+    *lo = (int32_t)nearbyint(ldexp(x - ldexp(h, kE), RJ_LO_BITS - kE)); /* x - hi 2^kE is exact in f64 */
+}
+
+void orc_rj_energy_levels(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                          const double *biases, int32_t *jhi, int32_t *jlo, int32_t *hhi, int32_t *hlo, int *kE_out)
+{
+    adjacency A;
+    adj_build(&A, n_edges, ea, eb, ej, nvars);
+    rj_scales S;
+    rj_analyse(&A, nvars, biases, &S);
+    adj_free(&A);
+    free(S.ksite);
+    if (kE_out) *kE_out = S.kE;
+    for (size_t e = 0; e < n_edges; e++) {
+        if (ea[e] == eb[e]) { jhi[e] = jlo[e] = 0; continue; }
+        rj_two_levels(ej[e], S.kE, &jhi[e], &jlo[e]);
+    }
+    for (size_t i = 0; i < nvars; i++) {
+        hhi[i] = hlo[i] = 0;
+        if (biases) rj_two_levels(biases[i], S.kE, &hhi[i], &hlo[i]);
+    }
+}
+
+/* eligibility for this path (see the header of this engine) */
 int orc_rj_eligible(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
                     const double *biases)
 {
     adjacency A;
     adj_build(&A, n_edges, ea, eb, ej, nvars);
-    double fmax = 0.0;
-    size_t terms = 0, maxdeg = 0;
-    double *mags = malloc((n_edges + nvars + 1) * sizeof(double));
-    for (size_t i = 0; i < nvars; i++) {
-        double f = biases ? fabs(biases[i]) : 0.0;
-        if (f != 0.0) mags[terms++] = f;
-        for (size_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) f += fabs(A.w[e]);
-        if (f > fmax) fmax = f;
-        if (A.ptr[i + 1] - A.ptr[i] > maxdeg) maxdeg = A.ptr[i + 1] - A.ptr[i];
-    }
+    rj_scales S;
+    rj_analyse(&A, nvars, biases, &S);
     adj_free(&A);
-    for (size_t e = 0; e < n_edges; e++)
-        if (ea[e] != eb[e] && ej[e] != 0.0) mags[terms++] = fabs(ej[e]);
-    double median = 0.0;
-    if (terms) {
-        qsort(mags, terms, sizeof(double), cmp_double);
-        median = mags[(terms - 1) / 2];
-    }
-    free(mags);
-    return maxdeg <= RJ_MAX_DEG && fmax > 0.0 && fmax <= 64.0 * median;
+    free(S.ksite);
+    return S.maxdeg <= RJ_MAX_DEG && S.fmax > 0.0 && S.dominated;
 }
 
 void orc_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
@@ -983,23 +1061,49 @@ void orc_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
     *mant_out = mant;
 }
 
-int orc_rj_accept(int32_t X, uint32_t u, uint32_t shift, uint32_t mant)
+/* d: the site's shift d_i (0 unless the site is heavy).  X is in units of 2^(k0 + d): of the d binary places between the
+ * site's scale and the graph's, as many as possible come off the right shift of X (m = min(shift, d)), the rest off the bound */
+int orc_rj_accept(int32_t X, uint32_t u, uint32_t shift, uint32_t mant, uint32_t d)
 {
-    int32_t xs = X >> shift; /* arithmetic */
+    uint32_t m = shift < d ? shift : d;
+    int32_t xs = X >> (shift - m); /* arithmetic */
     uint32_t xpos = xs > 0 ? (uint32_t)xs : 0u;
     uint32_t y = (uint32_t)(((uint64_t)orc_rj_lambda(u) * mant) >> 32);
-    return xpos <= y;
+    return xpos <= (y >> (d - m));
 }
 
-/* E = 2^k (sum_bonds Jq s s - sum_i hq s) + self-loop constant: an exact integer sum, so any order gives the same bits */
-static double rj_energy(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const int32_t *jq_edge, size_t nvars,
-                        const int32_t *hq, int k, double self_energy, const uint8_t *s)
+/* E = 2^kE S(hi) + 2^(kE - 24) S(lo) + self-loop constant, S(q) = sum_bonds q s s - sum_i q_i s_i: exact integer sums, so any
+ * order gives the same bits */
+static double rj_energy(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const int32_t *jhi, const int32_t *jlo,
+                        size_t nvars, const int32_t *hhi, const int32_t *hlo, int kE, double self_energy, const uint8_t *s)
 {
-    int64_t eq = 0;
+    int64_t shi = 0, slo = 0;
     for (size_t e = 0; e < n_edges; e++)
-        if (ea[e] != eb[e]) eq += (int64_t)jq_edge[e] * ((s[ea[e]] != 0) == (s[eb[e]] != 0) ? 1 : -1);
-    for (size_t i = 0; i < nvars; i++) eq -= (int64_t)hq[i] * (s[i] ? 1 : -1);
-    return ldexp((double)eq, k) + self_energy;
+        if (ea[e] != eb[e]) {
+            int par = (s[ea[e]] != 0) == (s[eb[e]] != 0) ? 1 : -1;
+            shi += (int64_t)jhi[e] * par;
+            slo += (int64_t)jlo[e] * par;
+        }
+    for (size_t i = 0; i < nvars; i++) {
+        shi -= (int64_t)hhi[i] * (s[i] ? 1 : -1);
+        slo -= (int64_t)hlo[i] * (s[i] ? 1 : -1);
+    }
+    return (ldexp((double)shi, kE) + ldexp((double)slo, kE - RJ_LO_BITS)) + self_energy;
+}
+
+double orc_rj_energy(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const double *ej, size_t nvars,
+                     const double *biases, const uint8_t *state)
+{
+    int32_t *jhi = malloc((n_edges ? n_edges : 1) * 4), *jlo = malloc((n_edges ? n_edges : 1) * 4);
+    int32_t *hhi = malloc((nvars ? nvars : 1) * 4), *hlo = malloc((nvars ? nvars : 1) * 4);
+    int kE;
+    orc_rj_energy_levels(n_edges, ea, eb, ej, nvars, biases, jhi, jlo, hhi, hlo, &kE);
+    double self_energy = 0.0;
+    for (size_t e = 0; e < n_edges; e++)
+        if (ea[e] == eb[e]) self_energy += ej[e];
+    double E = rj_energy(n_edges, ea, eb, jhi, jlo, nvars, hhi, hlo, kE, self_energy, state);
+    free(jhi); free(jlo); free(hhi); free(hlo);
+    return E;
 }
 
 /* states: uint8[32*G][nvars] as engine D; betas per timestep, or beta_replica[R] (padding replicas of the
@@ -1011,21 +1115,22 @@ void orc_rj_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
 {
     gen_graph G;
     gen_build(&G, n_edges, ea, eb, ej, nvars);
-    int k;
-    int32_t *jq_edge = malloc((n_edges ? n_edges : 1) * sizeof(int32_t)), *hq = malloc((nvars ? nvars : 1) * sizeof(int32_t));
-    orc_rj_quantise(n_edges, ea, eb, ej, nvars, biases, jq_edge, hq, &k);
-    /* quantised couplings in adjacency order (adj_build's fill order) */
-    int32_t *jq = malloc((G.A.ptr[nvars] ? G.A.ptr[nvars] : 1) * sizeof(int32_t));
-    {
-        size_t *fill = malloc((nvars + 1) * sizeof(size_t));
-        memcpy(fill, G.A.ptr, (nvars + 1) * sizeof(size_t));
-        for (size_t e = 0; e < n_edges; e++) {
-            if (ea[e] == eb[e]) continue;
-            jq[fill[ea[e]]++] = jq_edge[e];
-            jq[fill[eb[e]]++] = jq_edge[e];
-        }
-        free(fill);
+    rj_scales SC;
+    rj_analyse(&G.A, nvars, biases, &SC);
+    const int k = SC.k0;
+    /* couplings in adjacency order, each as seen from the row's site; biases; shifts */
+    size_t nnz = G.A.ptr[nvars];
+    int32_t *jq = malloc((nnz ? nnz : 1) * sizeof(int32_t)), *hq = malloc((nvars ? nvars : 1) * sizeof(int32_t));
+    uint32_t *dsh = malloc((nvars ? nvars : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < nvars; i++) {
+        for (size_t e = G.A.ptr[i]; e < G.A.ptr[i + 1]; e++) jq[e] = (int32_t)nearbyint(ldexp(G.A.w[e], -SC.ksite[i]));
+        hq[i] = biases ? (int32_t)nearbyint(ldexp(biases[i], -SC.ksite[i])) : 0;
+        dsh[i] = (uint32_t)(SC.ksite[i] - k > 31 ? 31 : SC.ksite[i] - k);
     }
+    int32_t *jhi = malloc((n_edges ? n_edges : 1) * 4), *jlo = malloc((n_edges ? n_edges : 1) * 4);
+    int32_t *hhi = malloc((nvars ? nvars : 1) * 4), *hlo = malloc((nvars ? nvars : 1) * 4);
+    int kE;
+    orc_rj_energy_levels(n_edges, ea, eb, ej, nvars, biases, jhi, jlo, hhi, hlo, &kE);
     double self_energy = 0.0;
     for (size_t e = 0; e < n_edges; e++)
         if (ea[e] == eb[e]) self_energy += ej[e];
@@ -1062,18 +1167,18 @@ void orc_rj_run(size_t n_edges, const uint64_t *ea, const uint64_t *eb, const do
                             field += (int64_t)jq[e] * (s[G.A.nbr[e]] ? 1 : -1);
                         int64_t X = (s[i] ? 1 : -1) * ((int64_t)hq[i] - field);
                         /* the sites of a colour class are independent: in place == simultaneous */
-                        if (orc_rj_accept((int32_t)X, words[b >> 2][b & 3], shift[b], mant[b])) s[i] = !s[i];
+                        if (orc_rj_accept((int32_t)X, words[b >> 2][b & 3], shift[b], mant[b], dsh[i])) s[i] = !s[i];
                     }
                 }
             if (energies_per_step)
                 for (int b = 0; b < 32 && 32 * g + b < R; b++)
                     energies_per_step[(32 * g + b) * timesteps + step] =
-                        rj_energy(n_edges, ea, eb, jq_edge, nvars, hq, k, self_energy, S + (size_t)b * nvars);
+                        rj_energy(n_edges, ea, eb, jhi, jlo, nvars, hhi, hlo, kE, self_energy, S + (size_t)b * nvars);
         }
         if (energies_out)
             for (int b = 0; b < 32 && 32 * g + b < R; b++)
-                energies_out[32 * g + b] = rj_energy(n_edges, ea, eb, jq_edge, nvars, hq, k, self_energy, S + (size_t)b * nvars);
+                energies_out[32 * g + b] = rj_energy(n_edges, ea, eb, jhi, jlo, nvars, hhi, hlo, kE, self_energy, S + (size_t)b * nvars);
     }
-    free(jq_edge); free(hq); free(jq);
+    free(jq); free(hq); free(dsh); free(jhi); free(jlo); free(hhi); free(hlo); free(SC.ksite);
     gen_free(&G);
 }

@@ -80,13 +80,17 @@ def lib():
         L.orc_rj_log_table.argtypes = [u32p]
         L.orc_rj_lambda.restype = C.c_uint32
         L.orc_rj_lambda.argtypes = [C.c_uint32]
-        L.orc_rj_quantise.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.orc_rj_quantise.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_int)]
+        L.orc_rj_energy_levels.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_rj_energy.restype = C.c_double
+        L.orc_rj_energy.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u8p]
         L.orc_rj_eligible.restype = C.c_int
         L.orc_rj_eligible.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p]
         L.orc_rj_beta.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_rj_accept.restype = C.c_int
-        L.orc_rj_accept.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_rj_accept.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_rj_run.argtypes = [C.c_size_t, u64p, u64p, f64p, C.c_size_t, C.c_void_p, u64p, C.c_size_t, C.c_int,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, u8p, C.c_void_p, C.c_void_p]
         L.orc_pt_swap_round.restype = C.c_uint64
@@ -274,11 +278,27 @@ def rj_lambda(u):
 
 
 def rj_quantise(ea, eb, ej, nvars, biases=None):
-    """(k, jq per input edge, hq per site): couplings as integers in units of 2^k."""
+    """(k0, jq[n_edges, 2], hq, dshift): the couplings of the dynamics as integers -- each bond as seen from its two ends (in
+    units of 2^(k0 + dshift[end])), the biases in units of 2^(k0 + dshift[i])."""
     b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
-    jq, hq, k = np.zeros(len(ea), dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int()
-    lib().orc_rj_quantise(len(ea), ea, eb, ej, nvars, _ptr(b), _ptr(jq), _ptr(hq), C.byref(k))
-    return k.value, jq, hq
+    jq, hq, d, k = np.zeros((len(ea), 2), dtype=np.int32), np.zeros(nvars, dtype=np.int32), np.zeros(nvars, dtype=np.uint8), C.c_int()
+    lib().orc_rj_quantise(len(ea), ea, eb, ej, nvars, _ptr(b), _ptr(jq), _ptr(hq), _ptr(d), C.byref(k))
+    return k.value, jq, hq, d
+
+
+def rj_energy_levels(ea, eb, ej, nvars, biases=None):
+    """(kE, jhi, jlo per input edge, hhi, hlo per site): x ~ hi 2^kE + lo 2^(kE - 24)."""
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    jhi, jlo = np.zeros(len(ea), dtype=np.int32), np.zeros(len(ea), dtype=np.int32)
+    hhi, hlo, k = np.zeros(nvars, dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int()
+    lib().orc_rj_energy_levels(len(ea), ea, eb, ej, nvars, _ptr(b), _ptr(jhi), _ptr(jlo), _ptr(hhi), _ptr(hlo), C.byref(k))
+    return k.value, jhi, jlo, hhi, hlo
+
+
+def rj_energy(ea, eb, ej, nvars, state, biases=None):
+    """Energy of a configuration as engine E reports it (two exact integer levels of the original couplings)."""
+    b = None if biases is None else np.ascontiguousarray(biases, dtype=np.float64)
+    return lib().orc_rj_energy(len(ea), ea, eb, ej, nvars, _ptr(b), np.ascontiguousarray(state, dtype=np.uint8))
 
 
 def rj_eligible(ea, eb, ej, nvars, biases=None):
@@ -292,8 +312,8 @@ def rj_beta(beta, k):
     return sh.value, mant.value
 
 
-def rj_accept(X, u, shift, mant):
-    return bool(lib().orc_rj_accept(C.c_int32(int(X)), C.c_uint32(int(u)), C.c_uint32(shift), C.c_uint32(mant)))
+def rj_accept(X, u, shift, mant, d=0):
+    return bool(lib().orc_rj_accept(C.c_int32(int(X)), C.c_uint32(int(u)), C.c_uint32(shift), C.c_uint32(mant), C.c_uint32(d)))
 
 
 def rj_run(ea, eb, ej, nvars, seeds, timesteps, betas=None, beta_replica=None, biases=None, states=None, t0=0, per_step=False):

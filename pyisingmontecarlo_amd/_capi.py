@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("ISINGMC_LIB_PATH") or os.path.join(_HERE, "lib", "lib
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = range(5)
 KIND_GENERAL, KIND_LATTICE2D = 0, 1
 FLAG_FORCE_GENERAL = 1
+FLAG_STABLE_PATH = 2
 
 
 class GraphInfo(C.Structure):
@@ -19,7 +20,8 @@ class GraphInfo(C.Structure):
                 ("n_colours", C.c_uint32), ("state_words", C.c_uint64), ("fast_path", C.c_int32), ("open_x", C.c_int32),
                 ("open_y", C.c_int32), ("field", C.c_double), ("jabs_y", C.c_double),
                 ("field_signs", C.c_int32), ("packed_degree", C.c_int32), ("real_slots", C.c_int32),
-                ("real_quantum_log2", C.c_int32)]
+                ("real_quantum_log2", C.c_int32), ("real_energy_log2", C.c_int32), ("real_heavy_sites", C.c_int32),
+                ("stable_path", C.c_int32)]
 
 
 _vp = C.c_void_p
@@ -36,8 +38,9 @@ _PROTOTYPES = {
     "isingmc_host_colour_graph": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint32)]),
     "isingmc_host_pt_swap_round": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp, _vp,
                                              C.POINTER(C.c_uint64)]),
-    "isingmc_host_rj_quantise": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.POINTER(C.c_int),
+    "isingmc_host_rj_quantise": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp, C.POINTER(C.c_int),
                                            C.POINTER(C.c_int)]),
+    "isingmc_host_rj_energy_levels": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     "isingmc_host_rj_beta": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "isingmc_host_rj_log_table": (C.c_int, [_vp]),
     "isingmc_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_uint, C.POINTER(_vp)]),
@@ -60,6 +63,8 @@ _PROTOTYPES = {
     "isingmc_states_set_timestep": (C.c_int, [_vp, C.c_uint64]),
     "isingmc_run_sampling": (C.c_int, [_vp, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
     "isingmc_pt_attach": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64]),
+    "isingmc_pt_can_attach": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]),
+    "isingmc_pt_detach": (C.c_int, [_vp]),
     "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "isingmc_pt_time_steps": (C.c_int, [_vp, C.c_size_t]),
     "isingmc_pt_measure": (C.c_int, [_vp]),
@@ -112,7 +117,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.isingmc_abi_version() != 3:
+        if L.isingmc_abi_version() != 4:
             raise RuntimeError("libisingmc.so ABI version mismatch")
         _lib = L
     return _lib
@@ -171,11 +176,22 @@ def recognise_lattice2d(ea, eb, ej, nvars):
 
 
 def rj_quantise(ea, eb, ej, nvars, biases=None):
-    """(k, jq per input edge, hq per site, eligible) of the real-coupling packed path."""
+    """(k, jq[n_edges, 2] (each bond as seen from its two ends), hq per site, dshift per site, eligible) of the real-coupling
+    packed path."""
     ea, eb, ej, b = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64), _arr(biases, np.float64)
-    jq, hq, k, ok = np.zeros(len(ea), dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int(), C.c_int()
-    _check(lib().isingmc_host_rj_quantise(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(b), _p(jq), _p(hq), C.byref(k), C.byref(ok)))
-    return k.value, jq, hq, bool(ok.value)
+    jq, hq, d = np.zeros((len(ea), 2), dtype=np.int32), np.zeros(nvars, dtype=np.int32), np.zeros(nvars, dtype=np.uint8)
+    k, ok = C.c_int(), C.c_int()
+    _check(lib().isingmc_host_rj_quantise(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(b), _p(jq), _p(hq), _p(d), C.byref(k), C.byref(ok)))
+    return k.value, jq, hq, d, bool(ok.value)
+
+
+def rj_energy_levels(ea, eb, ej, nvars, biases=None):
+    """(kE, jhi, jlo per input edge, hhi, hlo per site): the two integer levels of that path's energies."""
+    ea, eb, ej, b = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64), _arr(biases, np.float64)
+    jhi, jlo = np.zeros(len(ea), dtype=np.int32), np.zeros(len(ea), dtype=np.int32)
+    hhi, hlo, k = np.zeros(nvars, dtype=np.int32), np.zeros(nvars, dtype=np.int32), C.c_int()
+    _check(lib().isingmc_host_rj_energy_levels(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(b), _p(jhi), _p(jlo), _p(hhi), _p(hlo), C.byref(k)))
+    return k.value, jhi, jlo, hhi, hlo
 
 
 def rj_beta(beta, k):
@@ -216,14 +232,15 @@ def release_cached_resources():
 class Graph:
     """isingmc_graph: edges (+ biases) resident on one device."""
 
-    def __init__(self, ea, eb, ej, nvars=None, biases=None, device=0, force_general=False):
+    def __init__(self, ea, eb, ej, nvars=None, biases=None, device=0, force_general=False, stable_path=False):
         self._h = _vp()
         ea, eb, ej = _arr(ea, np.uint64), _arr(eb, np.uint64), _arr(ej, np.float64)
         if nvars is None:
             nvars = int(max(ea.max(), eb.max())) + 1 if len(ea) else 0
         biases = _arr(biases, np.float64)
         _check(lib().isingmc_graph_create(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(biases), device,
-                                          FLAG_FORCE_GENERAL if force_general else 0, C.byref(self._h)))
+                                          (FLAG_FORCE_GENERAL if force_general else 0) | (FLAG_STABLE_PATH if stable_path else 0),
+                                          C.byref(self._h)))
         info = GraphInfo()
         _check(lib().isingmc_graph_info(self._h, C.byref(info)))
         self.info = info
@@ -355,6 +372,15 @@ class States:
                                        C.c_uint64(int(seed))))
         self._pt_rungs = len(b)
         self._pt_world = world_size
+
+    def pt_can_attach(self, n_rungs, slot_offset, slots_per_rank, world_size):
+        """Would pt_attach accept this container and ladder geometry?  No side effects."""
+        ok = C.c_int()
+        _check(lib().isingmc_pt_can_attach(self._h, n_rungs, slot_offset, slots_per_rank, world_size, C.byref(ok)))
+        return bool(ok.value)
+
+    def pt_detach(self):
+        _check(lib().isingmc_pt_detach(self._h))
 
     def pt_buffers(self):
         """(local, all) as torch CUDA tensors viewing the engine's device buffers (no copy)."""

@@ -274,7 +274,7 @@ RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases)
 {
     RjQuant Q;
     double fmax = 0.0;
-    std::vector<double> mags; // nonzero |coupling| (every bond once) and |bias|
+    std::vector<double> mags, F(nvars, 0.0); // mags: nonzero |coupling| (every bond once) and |bias|
     for (size_t i = 0; i < nvars; i++) {
         double f = biases ? std::fabs(biases[i]) : 0.0;
         if (f != 0.0) mags.push_back(f);
@@ -283,21 +283,50 @@ RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases)
             // every bond sits in the adjacency twice: taken from its lower-numbered end (duplicated bonds are separate terms)
             if (A.nbr[e] > i && A.w[e] != 0.0) mags.push_back(std::fabs(A.w[e]));
         }
+        F[i] = f;
         fmax = std::max(fmax, f);
         Q.max_degree = std::max<uint32_t>(Q.max_degree, uint32_t(A.ptr[i + 1] - A.ptr[i]));
     }
-    Q.k = fmax > 0.0 ? std::ilogb(fmax) + 1 - 30 : 0;
-    Q.jq.resize(A.w.size());
-    for (size_t e = 0; e < A.w.size(); e++) Q.jq[e] = int32_t(std::nearbyint(std::ldexp(A.w[e], -Q.k)));
-    Q.hq.assign(nvars, 0);
-    if (biases)
-        for (size_t i = 0; i < nvars; i++) Q.hq[i] = int32_t(std::nearbyint(std::ldexp(biases[i], -Q.k)));
     double median = 0.0; // the lower median
     if (!mags.empty()) {
         std::nth_element(mags.begin(), mags.begin() + (mags.size() - 1) / 2, mags.end());
         median = mags[(mags.size() - 1) / 2];
     }
-    Q.eligible = Q.max_degree <= 15 && fmax > 0.0 && fmax <= 64.0 * median;
+    // the graph's quantum: from the largest local field, but never coarser than 2^-24 of the typical (median) term; sites whose
+    // local field is beyond that range (one pinning bias, one enormous bond) are HEAVY: they quantise at their own scale k_i
+    const double fbase = std::min(fmax, 64.0 * median);
+    Q.k = fbase > 0.0 ? std::ilogb(fbase) + 1 - 30 : 0;
+    Q.k_energy = fmax > 0.0 ? std::ilogb(fmax) + 2 - 30 : 0;
+    Q.jq.resize(A.w.size());
+    Q.hq.assign(nvars, 0);
+    Q.dshift.assign(nvars, 0);
+    bool dominated = true;
+    for (size_t i = 0; i < nvars; i++) {
+        const int ki = std::max(Q.k, F[i] > 0.0 ? std::ilogb(F[i]) + 1 - 30 : Q.k);
+        if (ki > Q.k) {
+            Q.heavy = true;
+            Q.dshift[i] = uint8_t(std::min(ki - Q.k, 31));
+            double m = biases ? std::fabs(biases[i]) : 0.0;
+            for (uint64_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) m = std::max(m, std::fabs(A.w[e]));
+            dominated &= 4.0 * m >= 3.0 * F[i]; // then |X_i| >= F_i / 2 whatever the spins
+        }
+        for (uint64_t e = A.ptr[i]; e < A.ptr[i + 1]; e++) Q.jq[e] = int32_t(std::nearbyint(std::ldexp(A.w[e], -ki)));
+        if (biases) Q.hq[i] = int32_t(std::nearbyint(std::ldexp(biases[i], -ki)));
+    }
+    // the energy of the ORIGINAL couplings in two integer levels: x ~ hi 2^kE + lo 2^(kE - 24)
+    const auto levels = [&](double x, int32_t *hi, int32_t *lo) {
+        const double h = std::nearbyint(std::ldexp(x, -Q.k_energy));
+        *hi = int32_t(h);
+        *lo = int32_t(std::nearbyint(std::ldexp(x - std::ldexp(h, Q.k_energy), RJ_ENERGY_LO_BITS - Q.k_energy)));
+    };
+    Q.jhi.resize(A.w.size());
+    Q.jlo.resize(A.w.size());
+    for (size_t e = 0; e < A.w.size(); e++) levels(A.w[e], &Q.jhi[e], &Q.jlo[e]);
+    Q.hhi.assign(nvars, 0);
+    Q.hlo.assign(nvars, 0);
+    if (biases)
+        for (size_t i = 0; i < nvars; i++) levels(biases[i], &Q.hhi[i], &Q.hlo[i]);
+    Q.eligible = Q.max_degree <= 31 && fmax > 0.0 && dominated;
     return Q;
 }
 

@@ -65,15 +65,20 @@ uint64_t pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const doub
                        const double *slot_energy, uint32_t *perm);
 
 // ---- replica-packed real-coupling path: host halves of the spec ---------------------------
-// Couplings and biases as integers in units of 2^k: k = ilogb(Fmax) + 1 - 30, Fmax = max_i (|h_i| + sum_e |J_e|);
-// jq in ADJACENCY order (A.w's), hq per site.  eligible: degree <= 15, Fmax > 0 and Fmax <= 64 x the median nonzero
-// |coupling or bias| (the absolute rounding error 2^(k-1) of a coupling then stays below 2^-25 of that median; one
-// enormous bias or coupling would otherwise set a quantum that wipes out the ordinary ones).
+// Scales: F_i = |h_i| + sum_e |J_e|, Fmax = max F_i, med = the lower median nonzero |coupling or bias|;
+// k = ilogb(min(Fmax, 64 med)) + 1 - 30 is the graph's quantum; site i quantises what it sees at k_i = max(k, ilogb(F_i) + 1 - 30)
+// (dshift[i] = min(k_i - k, 31); > 0: a HEAVY site -- one pinning bias, one enormous bond): jq in ADJACENCY order (A.w's, each
+// entry as seen from its row's site), hq per site.  eligible: degree <= 31, Fmax > 0, and every heavy site dominated by one
+// term (4 max term >= 3 F_i: no cancellation among its large terms can make the coarser quantum matter).
+// Energy levels (the ORIGINAL couplings, not the dynamics' rounded ones): k_energy = ilogb(Fmax) + 2 - 30,
+// x ~ hi 2^k_energy + lo 2^(k_energy - 24); jhi / jlo in adjacency order (one value per bond), hhi / hlo per site.
+constexpr int RJ_ENERGY_LO_BITS = 24;
 struct RjQuant {
-    bool eligible = false;
-    int k = 0;
+    bool eligible = false, heavy = false;
+    int k = 0, k_energy = 0;
     uint32_t max_degree = 0;
-    std::vector<int32_t> jq, hq;
+    std::vector<int32_t> jq, hq, jhi, jlo, hhi, hlo;
+    std::vector<uint8_t> dshift;
 };
 RjQuant rj_quantise(const Adjacency &A, size_t nvars, const double *biases);
 // acceptance scale of beta: accept iff max(X >> shift, 0) <= (Lambda_q(u) * mant) >> 32

@@ -338,8 +338,12 @@ struct isingmc_graph {
     uint64_t n_directed = 0;
     // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 15
     bool rj_ok = false;
-    RjGraphDev rj{};
-    int rj_k = 0;                         // couplings are integers in units of 2^rj_k
+    RjGraphDev rj{};                      // the dynamics' view
+    RjGraphDev rj_hi{}, rj_lo{};          // the same topology with the two integer levels of the ORIGINAL couplings (energies)
+    int rj_k = 0;                         // the dynamics' couplings are integers in units of 2^rj_k (heavy sites: 2^(rj_k + dshift))
+    int rj_k_energy = 0;                  // energy = 2^rj_k_energy S(hi) + 2^(rj_k_energy - 24) S(lo)
+    uint32_t rj_heavy_sites = 0;
+    bool stable_path = false;             // ISINGMC_FLAG_STABLE_PATH: the kernel family never depends on the number of experiments
     std::vector<uint32_t> class_real_end; // per colour class: end of its real sites (the padding follows)
     std::vector<void *> dev_allocs;
 
@@ -757,8 +761,42 @@ extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t 
     return ISINGMC_OK;
 }
 
+// adjacency order -> input-edge order: edge e is the next unfilled entry of both its ends' rows
+template <typename F>
+static void for_each_input_edge(const Adjacency &A, const uint64_t *ea, const uint64_t *eb, size_t n_edges, F &&f)
+{
+    std::vector<uint64_t> fill(A.ptr.begin(), A.ptr.end());
+    for (size_t e = 0; e < n_edges; e++) {
+        if (ea[e] == eb[e]) { f(e, false, 0, 0); continue; }
+        f(e, true, fill[ea[e]], fill[eb[e]]);
+        fill[ea[e]]++;
+        fill[eb[e]]++;
+    }
+}
+
+extern "C" int isingmc_host_rj_energy_levels(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars,
+                                             const double *biases, int32_t *jhi_out, int32_t *jlo_out, int32_t *hhi_out,
+                                             int32_t *hlo_out, int *k_energy_out)
+{
+    TRY(check_edges(ea, eb, ej, n_edges, nvars));
+    if (biases)
+        for (size_t i = 0; i < nvars; i++)
+            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
+    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
+    const RjQuant Q = rj_quantise(A, nvars, biases);
+    if (k_energy_out) *k_energy_out = Q.k_energy;
+    if (hhi_out) std::copy(Q.hhi.begin(), Q.hhi.end(), hhi_out);
+    if (hlo_out) std::copy(Q.hlo.begin(), Q.hlo.end(), hlo_out);
+    for_each_input_edge(A, ea, eb, n_edges, [&](size_t e, bool bond, uint64_t ia, uint64_t) {
+        if (jhi_out) jhi_out[e] = bond ? Q.jhi[ia] : 0;
+        if (jlo_out) jlo_out[e] = bond ? Q.jlo[ia] : 0;
+    });
+    return ISINGMC_OK;
+}
+
 extern "C" int isingmc_host_rj_quantise(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars,
-                                        const double *biases, int32_t *jq_out, int32_t *hq_out, int *k_out, int *eligible_out)
+                                        const double *biases, int32_t *jq_out, int32_t *hq_out, uint8_t *dshift_out, int *k_out,
+                                        int *eligible_out)
 {
     TRY(check_edges(ea, eb, ej, n_edges, nvars));
     if (biases)
@@ -769,15 +807,12 @@ extern "C" int isingmc_host_rj_quantise(const uint64_t *ea, const uint64_t *eb, 
     if (k_out) *k_out = Q.k;
     if (eligible_out) *eligible_out = Q.eligible;
     if (hq_out) std::copy(Q.hq.begin(), Q.hq.end(), hq_out);
-    if (jq_out) { // adjacency order -> input-edge order: edge e is the next unfilled entry of its first end's row
-        std::vector<uint64_t> fill(A.ptr.begin(), A.ptr.end());
-        for (size_t e = 0; e < n_edges; e++) {
-            if (ea[e] == eb[e]) { jq_out[e] = 0; continue; }
-            jq_out[e] = Q.jq[fill[ea[e]]];
-            fill[ea[e]]++;
-            fill[eb[e]]++;
-        }
-    }
+    if (dshift_out) std::copy(Q.dshift.begin(), Q.dshift.end(), dshift_out);
+    if (jq_out)
+        for_each_input_edge(A, ea, eb, n_edges, [&](size_t e, bool bond, uint64_t ia, uint64_t ib) {
+            jq_out[2 * e] = bond ? Q.jq[ia] : 0;
+            jq_out[2 * e + 1] = bond ? Q.jq[ib] : 0;
+        });
     return ISINGMC_OK;
 }
 
@@ -1052,18 +1087,27 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
     if ((!g->packed_ok || env_flag("ISINGMC_FORCE_REAL")) && n_pos < 0x80000000u) {
         const RjQuant Q = rj_quantise(A, nvars, biases);
         if (Q.eligible) {
-            const uint32_t slots = Q.max_degree <= 4 ? 4u : Q.max_degree <= 7 ? 7u : Q.max_degree <= 11 ? 11u : 15u;
+            const uint32_t slots = Q.max_degree <= 4 ? 4u : Q.max_degree <= 7 ? 7u : Q.max_degree <= 11 ? 11u : Q.max_degree <= 15 ? 15u
+                                   : Q.max_degree <= 23 ? 23u : 31u;
             std::vector<uint32_t> enbr(size_t(slots) * n_pos);
             std::vector<int32_t> ejq(size_t(slots) * n_pos, 0), ehq(n_pos, 0);
+            std::vector<int32_t> ejhi(size_t(slots) * n_pos, 0), ejlo(size_t(slots) * n_pos, 0), ehhi(n_pos, 0), ehlo(n_pos, 0);
+            std::vector<uint8_t> edsh(n_pos, 0);
             for (uint32_t i = 0; i < slots; i++)
                 for (uint32_t p = 0; p < n_pos; p++) enbr[size_t(i) * n_pos + p] = p; // unused slots point at the own position
             for (uint32_t p = 0; p < n_pos; p++) {
                 if (site[p] == PAD_SITE) continue;
                 ehq[p] = Q.hq[site[p]];
+                ehhi[p] = Q.hhi[site[p]];
+                ehlo[p] = Q.hlo[site[p]];
+                edsh[p] = Q.dshift[site[p]];
+                g->rj_heavy_sites += Q.dshift[site[p]] != 0;
                 uint32_t i = 0;
                 for (uint64_t e = A.ptr[site[p]]; e < A.ptr[site[p] + 1]; e++, i++) {
                     enbr[size_t(i) * n_pos + p] = uint32_t(C.pos[A.nbr[e]]);
                     ejq[size_t(i) * n_pos + p] = Q.jq[e];
+                    ejhi[size_t(i) * n_pos + p] = Q.jhi[e];
+                    ejlo[size_t(i) * n_pos + p] = Q.jlo[e];
                 }
             }
             uint32_t lt[RJ_LOG_INTERVALS + 1];
@@ -1075,9 +1119,17 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
             TRY(graph_upload(g, &J.jq, ejq));
             TRY(graph_upload(g, &J.hq, ehq));
             TRY(graph_upload(g, &J.logtab, logtab));
+            J.dshift = nullptr;
+            if (Q.heavy) TRY(graph_upload(g, &J.dshift, edsh));
             J.n_pos = n_pos;
             J.slots = slots;
+            g->rj_hi = g->rj_lo = J;
+            TRY(graph_upload(g, &g->rj_hi.jq, ejhi));
+            TRY(graph_upload(g, &g->rj_hi.hq, ehhi));
+            TRY(graph_upload(g, &g->rj_lo.jq, ejlo));
+            TRY(graph_upload(g, &g->rj_lo.hq, ehlo));
             g->rj_k = Q.k;
+            g->rj_k_energy = Q.k_energy;
             g->rj_ok = true;
             // the packed containers' common parts (random start, set_state, copy-out) read these
             g->pk.site = D.site;
@@ -1114,6 +1166,7 @@ extern "C" int isingmc_graph_create(const uint64_t *ea, const uint64_t *eb, cons
     g->nvars = nvars;
     g->n_edges = n_edges;
     g->has_bias = has_bias;
+    g->stable_path = (flags & ISINGMC_FLAG_STABLE_PATH) != 0 || env_flag("ISINGMC_STABLE_PATH");
     Lattice2D L;
     bool field_signs = false;
     const double h = has_bias ? uniform_bias(biases, nvars, &field_signs) : 0.0;
@@ -1148,6 +1201,9 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
     info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
     info->real_slots = g->rj_ok ? int32_t(g->rj.slots) : 0;
     info->real_quantum_log2 = g->rj_ok ? g->rj_k : 0;
+    info->real_energy_log2 = g->rj_ok ? g->rj_k_energy : 0;
+    info->real_heavy_sites = g->rj_ok ? int32_t(g->rj_heavy_sites) : 0;
+    info->stable_path = g->stable_path ? 1 : 0;
     info->state_words = g->state_words;
     return ISINGMC_OK;
 }
@@ -1220,6 +1276,11 @@ static int reserve(isingmc_states *s, size_t cap)
     } undo{&d_state, &d_keys};
     TRY(dev_alloc(&d_state, cap * g->state_words));
     TRY(dev_alloc(&d_keys, cap));
+    // enqueue-only calls (isingmc_pt_*, the sampling loop) may still be running on the engine's non-blocking stream, which the
+    // null-stream copies below are NOT ordered against; and the old blocks go back to the cache at the end
+    HIP_TRY(stream_quiesce(s->stream));
+    for (auto st : s->lanes) HIP_TRY(stream_quiesce(st));
+    if (s->copy_stream) HIP_TRY(stream_quiesce(s->copy_stream));
     if (s->R) {
         HIP_TRY(hipMemcpy(d_state, s->d_state, s->R * g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(d_keys, s->d_keys, s->R * sizeof(uint2), hipMemcpyDeviceToDevice));
@@ -1430,7 +1491,9 @@ static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real
     const uint64_t work = uint64_t(g->nvars) * n_replicas; // attempts per timestep
     const bool csr_resident = gen_resident_fits(g, n_replicas) && !resident_disabled();
     if (real_path) {
-        if (!csr_resident) return n_replicas >= 2; // partial groups draw only their own replicas' Philox calls: 1.4x the CSR launches at 2, 2.0x at 4, 2.9x at 8
+        // partial groups draw only their own replicas' Philox calls: 1.09x the CSR launches at ONE experiment (2048^2 Gaussian glass,
+        // profiles/r03_few_replicas.txt; re-measured in profiles/r04_real_eligibility.txt), 1.4x at 2, 2.0x at 4, 2.9x at 8
+        if (!csr_resident) return n_replicas >= 1;
         return n_replicas >= 16 && (g->nvars >= 8000 || (g->nvars >= 1500 && work >= (uint64_t(3) << 19))); // 1.5 x 2^20: re-measured with the graph staged in LDS
     }
     return work >= (uint64_t(1) << (csr_resident ? 22 : 19));
@@ -1440,13 +1503,14 @@ static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real
 static int choose_packed(const isingmc_graph *g, size_t n_replicas)
 {
     if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL") && (!g->packed_ok || env_flag("ISINGMC_FORCE_REAL"))) {
-        if (env_flag("ISINGMC_FORCE_REAL")) return n_replicas > 0 ? 2 : 0;
+        // (stable_path: the family follows from the graph alone -- experiment k must not change when the call asks for more of them)
+        if (env_flag("ISINGMC_FORCE_REAL") || g->stable_path) return n_replicas > 0 ? 2 : 0;
         return packed_worth_it(g, n_replicas, true) ? 2 : 0;
     }
     if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
-    if (env_flag("ISINGMC_FORCE_PACKED")) return n_replicas > 0 ? 1 : 0;
+    if (env_flag("ISINGMC_FORCE_PACKED") || g->stable_path) return n_replicas > 0 ? 1 : 0;
     return packed_worth_it(g, n_replicas, false) ? 1 : 0;
 }
 
@@ -1501,11 +1565,12 @@ static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first,
     return ISINGMC_OK;
 }
 
-// ClassicIsing.add_graph (classicising.rs:62-79) on a replica-packed container.  A group simulates all of its 32 bit
-// positions from the moment it is created (the spec numbers ties / draws words over whole groups), so a replica appended
-// into a partly filled group takes over the chain its bit position has been running since then -- a configuration
-// evolved under the same dynamics, i.e. as good a start as a fresh random one, and what the oracle engines give for the
-// final replica count; with an initial_state it is set explicitly.  Replica 32 g opens a new group keyed by its seed,
+// ClassicIsing.add_graph (classicising.rs:62-79) on a replica-packed container.  A replica appended into a partly filled
+// group starts from the random start of its bit position (the "PKIN" words of the group's key) NOW, at the current timestep --
+// a fresh experiment, as GraphState::new gives the reference (classicising.rs:73) and as every other path here does; with an
+// initial_state it is set explicitly.  (Bit-sliced path: a group simulates all of its 32 bit positions from the moment it is
+// created -- the spec numbers ties over whole groups -- so until round 3 the new replica took over the chain its bit had been
+// running: a thermalised start where the caller asked for a random one.)  Replica 32 g opens a new group keyed by its seed,
 // randomly started now.  Only whole containers grow (not shards of a larger set of experiments).
 static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state)
 {
@@ -1542,11 +1607,9 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
     }
     s->R = s->cap = s->n_total = slot + 1;
     if (initial_state) TRY(pk_set_state(s, slot, initial_state));
-    else if (s->rj && slot % 32 != 0) {
-        // real-coupling path: the bits of a group this container does not own are not simulated (rj_sweep_kernel PARTIAL), so the
-        // new replica's column holds whatever it held: it starts from its random start, like a replica appended on any other
-        // path.  (Bit-sliced path: the unused replicas of a group ARE simulated -- the group's tie numbering needs them -- and
-        // the new replica continues that trajectory.)
+    else if (slot % 32 != 0) {
+        // (real-coupling path: the bits of a group this container does not own are not simulated at all, rj_sweep_kernel PARTIAL,
+        //  so the column holds whatever it held)
         hipLaunchKernelGGL(pk_init_replica_kernel, dim3((g->pk.n_pos + 255) / 256), dim3(256), 0, s->stream, s->d_state, g->pk, s->d_keys,
                            uint32_t(slot / 32), uint32_t(slot % 32));
         HIP_TRY(hipGetLastError());
@@ -1581,7 +1644,7 @@ static int pk_set_betas(isingmc_states *s)
             rj_beta(s->betas[r], s->g->rj_k, &tab[sl].shift, &tab[sl].mant);
         }
         if (!s->d_rj_betas) TRY(dev_alloc(&s->d_rj_betas, tab.size()));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream)); // no launch may still be reading the old scales
         HIP_TRY(hipMemcpy(s->d_rj_betas, tab.data(), tab.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
         return ISINGMC_OK;
     }
@@ -1656,11 +1719,13 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
 
 static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up = true);
 
-// energy of one replica of a packed container from the first counter of its slot
-static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0)
+// energy of one replica of a packed container from the counters of its slot
+static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0, unsigned long long c1)
 {
-    // real-coupling path: c0 = -2 x the energy in units of 2^k (an exact, even integer; rj_measure_kernel)
-    if (rj) return std::ldexp(double(-(int64_t(c0) / 2)), g->rj_k) + g->self_energy;
+    // real-coupling path: c0, c1 = -2 x the hi / lo level sums of the energy (exact, even integers; rj_measure_kernel, run once
+    // per level): E = (2^kE hi + 2^(kE - 24) lo) + self loops -- the energy of the ORIGINAL couplings to Fmax 2^-54 per term
+    if (rj) return (std::ldexp(double(-(int64_t(c0) / 2)), g->rj_k_energy) + std::ldexp(double(-(int64_t(c1) / 2)), g->rj_k_energy - RJ_ENERGY_LO_BITS)) + g->self_energy;
+    (void)c1;
     // bit-sliced path: E = |J| (undirected bonds - 2 satisfied) + self loops; c0 = directed satisfied count (doubled)
     return g->jabs * (double(int64_t(g->n_directed / 2)) - double(int64_t(c0))) + g->self_energy;
 }
@@ -1669,6 +1734,10 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
+    if (s->rj && energies && mags) { // the second counter of a slot holds the lo level of the energy OR the up spins
+        TRY(pk_measure(s, energies, nullptr));
+        return pk_measure(s, nullptr, mags);
+    }
     TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/mags != nullptr));
     s->meas_zero = false;
     std::vector<unsigned long long> h(2 * s->pk_slots());
@@ -1676,7 +1745,7 @@ static int pk_measure(isingmc_states *s, double *energies, int64_t *mags)
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (size_t r = 0; r < R; r++) {
         const size_t sl = r + s->pk_bit0;
-        if (energies) energies[r] = pk_energy(g, s->rj, h[2 * sl]);
+        if (energies) energies[r] = pk_energy(g, s->rj, h[2 * sl], h[2 * sl + 1]);
         if (mags) mags[r] = 2 * int64_t(h[2 * sl + 1]) - int64_t(g->nvars);
     }
     return ISINGMC_OK;
@@ -1764,7 +1833,8 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             HIP_TRY(hipStreamSynchronize(s->stream));
             for (size_t k = 0; k < nk; k++)
                 for (size_t r = 0; r < R; r++)
-                    energies_per_step[r * timesteps + k0 + k] = pk_energy(g, s->rj, h_step_counts[(k * CS + r + s->pk_bit0) * 2]);
+                    energies_per_step[r * timesteps + k0 + k] = pk_energy(g, s->rj, h_step_counts[(k * CS + r + s->pk_bit0) * 2],
+                                                                          h_step_counts[(k * CS + r + s->pk_bit0) * 2 + 1]);
         } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) {
             // the next chunk overwrites the step tables: every lane must have finished reading them
             if (s->n_lanes > 1) { TRY(lanes_join(s)); HIP_TRY(hipStreamSynchronize(s->stream)); TRY(lanes_fork(s, want_lanes)); }
@@ -2635,11 +2705,11 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
             // all workgroups resident at once (the runtime's occupancy figure for this instantiation), every one walks its
             // share of the blocks; a grid one round and a bit long would run its tail at a fraction of the chip
             static std::mutex per_cu_mutex; // (the device fan-out measures from several host threads)
-            static int per_cu[4][2][2] = {};
+            static int per_cu[6][2][2] = {};
             int pc;
             {
                 std::lock_guard<std::mutex> lock(per_cu_mutex);
-                int &slot = per_cu[g->rj.slots == 4 ? 0 : g->rj.slots == 7 ? 1 : g->rj.slots == 11 ? 2 : 3][bip][want_up];
+                int &slot = per_cu[g->rj.slots == 4 ? 0 : g->rj.slots == 7 ? 1 : g->rj.slots == 11 ? 2 : g->rj.slots == 15 ? 3 : g->rj.slots == 23 ? 4 : 5][bip][want_up];
                 if (slot == 0) slot = std::max(1, rj_measure_blocks_per_cu(g->rj.slots, bip, want_up));
                 pc = slot;
             }
@@ -2651,8 +2721,12 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
             for (size_t g0 = 0; g0 < s->groups; g0 += MAX_GRID_Y) {
                 const size_t ng = std::min(MAX_GRID_Y, s->groups - g0);
                 const size_t gx = std::min(scan_blocks, std::max<size_t>(1, resident / ng));
-                HIP_TRY(rj_launch_measure(dim3(unsigned(std::max<size_t>(gx, 1)), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj,
+                // hi level (+ the up spins when wanted) into the first counter of a slot, lo level into the second
+                HIP_TRY(rj_launch_measure(dim3(unsigned(std::max<size_t>(gx, 1)), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj_hi,
                                           g->pk.site, class0_end, scan_end, want_up, counts_slot + 2 * 32 * g0));
+                if (!want_up)
+                    HIP_TRY(rj_launch_measure(dim3(unsigned(std::max<size_t>(gx, 1)), unsigned(ng)), s->stream, s->d_state + g0 * g->pk.n_pos, g->rj_lo,
+                                              g->pk.site, class0_end, scan_end, false, counts_slot + 2 * 32 * g0 + 1));
             }
             return ISINGMC_OK;
         }
@@ -2816,7 +2890,7 @@ static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalizati
                 const uint32_t *w = h_samples + k * words + (sl / 32) * g->pk.n_pos;
                 const uint32_t bit = uint32_t(sl % 32);
                 for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
-                energy = pk_energy(g, s->rj, h_counts[(k * CS + sl) * 2]);
+                energy = pk_energy(g, s->rj, h_counts[(k * CS + sl) * 2], h_counts[(k * CS + sl) * 2 + 1]);
             } else {
                 unpack_state(g, h_samples + k * words + r * g->state_words, out);
                 if (counts) energy = lattice_energy(g, h_counts[(k * R + r) * 2], h_counts[(k * R + r) * 2 + 1]);
@@ -2889,20 +2963,63 @@ static int pt_after_swap(isingmc_states *s)
     return ISINGMC_OK;
 }
 
+// why this container cannot take an on-stream ladder of that geometry ("" when it can): no side effects
+static std::string pt_attach_obstacle(const isingmc_states *s, size_t n_rungs, size_t slot_offset, size_t slots_per_rank, size_t world_size)
+{
+    if (s->pt_attached) return "a ladder is already attached";
+    const bool pk_ladder = s->packed && !s->rj;
+    if (!s->packed && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
+        return "on-stream tempering is implemented for periodic, field-free lattices and for the replica-packed "
+               "paths (use the host swap step)";
+    // the replicas of a bit-sliced group number their ties together: a shard must hold whole groups (distributed.block_size aligns them)
+    if (pk_ladder && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
+        return "a tempering shard on the replica-packed path must start and end on multiples of 32 slots";
+    if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
+        return "ladder / shard geometry mismatch";
+    return "";
+}
+
+extern "C" int isingmc_pt_can_attach(const isingmc_states *s, size_t n_rungs, size_t slot_offset, size_t slots_per_rank,
+                                     size_t world_size, int *ok_out)
+{
+    if (!s || !ok_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    const std::string why = pt_attach_obstacle(s, n_rungs, slot_offset, slots_per_rank, world_size);
+    *ok_out = why.empty() ? 1 : 0;
+    if (!why.empty()) g_last_error = why; // (informational: the call itself succeeded)
+    return ISINGMC_OK;
+}
+
+// the ladder's device buffers go back; the container keeps its configurations and timestep and takes uniform betas again
+extern "C" int isingmc_pt_detach(isingmc_states *s)
+{
+    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
+    if (!s->pt_attached) return ISINGMC_OK;
+    TRY(use_device(s->g->device));
+    HIP_TRY(hipStreamSynchronize(s->stream)); // enqueued rounds may still read the ladder
+    TRY(strip_error(strip_check(s)));
+    for (void **p : {(void **)&s->d_pt_ladder, (void **)&s->d_pt_local, (void **)&s->d_pt_all, (void **)&s->d_pt_ladder_thr,
+                     (void **)&s->d_pt_perm, (void **)&s->d_pt_counters, (void **)&s->d_pt_mail, (void **)&s->d_pt_round_counts,
+                     (void **)&s->d_pt_perm2}) {
+        if (*p) (void)cached_free(*p);
+        *p = nullptr;
+    }
+    s->pt = PtDev{};
+    s->pt_attached = false;
+    s->has_betas = false;
+    s->betas.clear();
+    s->meas_fresh = false;
+    return ISINGMC_OK;
+}
+
 extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
                                  size_t slots_per_rank, size_t world_size, uint64_t seed)
 {
     if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    if (s->pt_attached) return fail(ISINGMC_ERR_INVALID, "a ladder is already attached");
+    {
+        const std::string why = pt_attach_obstacle(s, n_rungs, slot_offset, slots_per_rank, world_size);
+        if (!why.empty()) return fail(ISINGMC_ERR_INVALID, why);
+    }
     const bool rj_ladder = s->packed && s->rj, pk_ladder = s->packed && !s->rj;
-    if (!s->packed && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
-        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for periodic, field-free lattices and for the replica-packed "
-                                         "paths (use the host swap step)");
-    // the replicas of a bit-sliced group number their ties together: a shard must hold whole groups (distributed.block_size aligns them)
-    if (pk_ladder && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
-        return fail(ISINGMC_ERR_INVALID, "a tempering shard on the replica-packed path must start and end on multiples of 32 slots");
-    if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
-        return fail(ISINGMC_ERR_INVALID, "ladder / shard geometry mismatch");
     for (size_t i = 0; i < n_rungs; i++)
         if (!std::isfinite(ladder_betas[i])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
     TRY(use_device(s->g->device));
@@ -3066,7 +3183,7 @@ extern "C" int isingmc_pt_measure(isingmc_states *s)
     } else if (s->packed && s->rj) {
         TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
         s->meas_zero = false;
-        HIP_TRY(rj_launch_energy_from_counts(s->stream, s->d_meas, uint32_t(s->pk_bit0), uint32_t(R), g->rj_k, g->self_energy,
+        HIP_TRY(rj_launch_energy_from_counts(s->stream, s->d_meas, uint32_t(s->pk_bit0), uint32_t(R), g->rj_k_energy, g->self_energy,
                                              s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local));
     } else {
         return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path and the real-coupling path; use the host swap step");

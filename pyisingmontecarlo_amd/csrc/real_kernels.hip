@@ -11,7 +11,9 @@ static void rj_with_slots(uint32_t slots, F &&f)
     if (slots == 4) f(std::integral_constant<int, 4>{});
     else if (slots == 7) f(std::integral_constant<int, 7>{});
     else if (slots == 11) f(std::integral_constant<int, 11>{});
-    else f(std::integral_constant<int, 15>{});
+    else if (slots == 15) f(std::integral_constant<int, 15>{});
+    else if (slots == 23) f(std::integral_constant<int, 23>{});
+    else f(std::integral_constant<int, 31>{});
 }
 
 uint32_t rj_threads(uint32_t slots)
@@ -31,8 +33,16 @@ hipError_t rj_launch_sweep(dim3 grid, hipStream_t stream, uint32_t *state, const
                                q_lo, q_hi);
         };
         const bool whole = q_lo == 0 && q_hi >= 8; // every replica bit of the groups of this launch is decided
-        if (beta_stride == 0) { if (whole) launch(rj_sweep_kernel<S, true, false>); else launch(rj_sweep_kernel<S, true, true>); }
-        else { if (whole) launch(rj_sweep_kernel<S, false, false>); else launch(rj_sweep_kernel<S, false, true>); }
+        const bool heavy = G.dshift != nullptr;
+        if (beta_stride == 0) {
+            if (!whole) launch(rj_sweep_kernel<S, true, true, true>);
+            else if (heavy) launch(rj_sweep_kernel<S, true, false, true>);
+            else launch(rj_sweep_kernel<S, true, false, false>);
+        } else {
+            if (!whole) launch(rj_sweep_kernel<S, false, true, true>);
+            else if (heavy) launch(rj_sweep_kernel<S, false, false, true>);
+            else launch(rj_sweep_kernel<S, false, false, false>);
+        }
     });
     return hipGetLastError();
 }
@@ -56,10 +66,10 @@ hipError_t rj_launch_measure(dim3 grid, hipStream_t stream, const uint32_t *stat
     return hipGetLastError();
 }
 
-hipError_t rj_launch_energy_from_counts(hipStream_t stream, unsigned long long *meas, uint32_t first_slot, uint32_t n, int k,
+hipError_t rj_launch_energy_from_counts(hipStream_t stream, unsigned long long *meas, uint32_t first_slot, uint32_t n, int k_energy,
                                         double self_energy, double *out)
 {
-    hipLaunchKernelGGL(rj_energy_from_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, meas, first_slot, n, k, self_energy, out);
+    hipLaunchKernelGGL(rj_energy_from_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, meas, first_slot, n, k_energy, self_energy, out);
     return hipGetLastError();
 }
 

@@ -4,7 +4,7 @@
 //
 // Layout as the packed path (packed_kernels.hpp): colour-major positions, one 32-bit word per POSITION holding the spins
 // of a group of 32 replicas.  One thread owns one position and decides its 32 replicas:
-//   1. gather the own word and the <= 7 neighbour words; a_e = own ^ neighbour_e (bit b: replica b's bond e is antiparallel);
+//   1. gather the own word and the neighbour words; a_e = own ^ neighbour_e (bit b: replica b's bond e is antiparallel);
 //   2. the half energy change of a flip, X = s (hq - sum_e Jq_e s_e) = (s hq) - sum_e Jq_e + 2 sum_{e: a_e} Jq_e, depends on
 //      the replica only through the index (a_0 .. a_{d-1}, own): its <= 32 values go into a per-thread column of LDS
 //      (layout [entry][thread]: conflict-free), built with 15 + 32 integer adds per 32 replicas;
@@ -52,17 +52,17 @@ __device__ __forceinline__ uint32_t rj_lambda(const uint32_t u, const uint2 *s_l
 }
 
 // Index of a replica at a position: bit e < SLOTS = a_e (bond e antiparallel), bit SLOTS = the own spin (bit 4 when SLOTS == 4).
-// SLOTS == 4: ONE table of 32 entries indexed by those 5 bits.  SLOTS == 7 / 11 / 15: the 8 / 12 / 16 index bits are cut into
-// 2 / 3 / 4 nibbles with a 16-entry table each, X = the sum of the nibbles' entries (the constant - sum_e Jq_e and the own
-// spin's +- hq live in the nibble that holds the own bit).
+// SLOTS == 4: ONE table of 32 entries indexed by those 5 bits.  SLOTS == 7 / 11 / 15 / 23 / 31: the 8 / 12 / 16 / 24 / 32 index
+// bits are cut into 2 / 3 / 4 / 6 / 8 nibbles with a 16-entry table each, X = the sum of the nibbles' entries (the constant
+// - sum_e Jq_e and the own spin's +- hq live in the nibble that holds the own bit).
 template <int SLOTS>
 struct RjShape {
-    static_assert(SLOTS == 4 || SLOTS == 7 || SLOTS == 11 || SLOTS == 15, "slots");
+    static_assert(SLOTS == 4 || SLOTS == 7 || SLOTS == 11 || SLOTS == 15 || SLOTS == 23 || SLOTS == 31, "slots");
     static constexpr int NIB = SLOTS == 4 ? 0 : (SLOTS + 4) / 4;      // nibble tables (0: the single 32-entry table)
     static constexpr int ENTRIES = SLOTS == 4 ? 32 : 16 * NIB;        // LDS words per thread
-    static constexpr int WORDS = SLOTS <= 7 ? 8 : 16;                 // index words before transposition
+    static constexpr int WORDS = SLOTS <= 7 ? 8 : SLOTS <= 15 ? 16 : SLOTS <= 23 ? 24 : 32; // index words before transposition
     static constexpr int OWN_BIT = SLOTS == 4 ? 4 : SLOTS;
-    static constexpr int THREADS = SLOTS <= 7 ? 256 : 128;            // workgroup size (48 / 64 table words per thread: half the threads)
+    static constexpr int THREADS = SLOTS <= 7 ? 256 : SLOTS <= 15 ? 128 : 64; // workgroup size (48 / 64, 96 / 128 table words per thread)
 };
 
 // The per-thread column of X values.  HSCALE: 1 for the sweep (X), 2 for the measurement of a general graph
@@ -71,18 +71,21 @@ template <int SLOTS, int HSCALE, bool FOLD>
 __device__ __forceinline__ void rj_build_tables(uint32_t *s_x, const uint32_t tid, const int32_t (&jq)[SLOTS], const int32_t hq,
                                                 const uint32_t shift)
 {
+    // (unsigned arithmetic throughout: 2 x a subset sum can pass 2^31 on the way to an X that fits int32 again -- wrap-around is
+    //  exact modulo 2^32, signed overflow would be undefined)
     using SH = RjShape<SLOTS>;
-    int32_t sj = 0;
+    uint32_t sj = 0;
 #pragma unroll
-    for (int e = 0; e < SLOTS; e++) sj += jq[e];
+    for (int e = 0; e < SLOTS; e++) sj += uint32_t(jq[e]);
+    const uint32_t hs = uint32_t(HSCALE) * uint32_t(hq);
     if constexpr (SLOTS == 4) {
-        int32_t sub[16]; // 2 x subset sums of the four couplings
+        uint32_t sub[16]; // 2 x subset sums of the four couplings
         sub[0] = 0;
 #pragma unroll
-        for (int n = 1; n < 16; n++) sub[n] = sub[n & (n - 1)] + 2 * jq[__builtin_ctz(n)];
+        for (int n = 1; n < 16; n++) sub[n] = sub[n & (n - 1)] + 2u * uint32_t(jq[__builtin_ctz(n)]);
 #pragma unroll
         for (int n = 0; n < 16; n++) {
-            const int32_t x0 = sub[n] - sj - HSCALE * hq, x1 = sub[n] - sj + HSCALE * hq; // own spin down / up
+            const int32_t x0 = int32_t(sub[n] - sj - hs), x1 = int32_t(sub[n] - sj + hs); // own spin down / up
             if constexpr (FOLD) {
                 s_x[n * RjShape<SLOTS>::THREADS + tid] = uint32_t(max(x0 >> shift, 0));
                 s_x[(16 + n) * RjShape<SLOTS>::THREADS + tid] = uint32_t(max(x1 >> shift, 0));
@@ -94,22 +97,21 @@ __device__ __forceinline__ void rj_build_tables(uint32_t *s_x, const uint32_t ti
     } else {
 #pragma unroll
         for (int nb = 0; nb < SH::NIB; nb++) {
-            int32_t sub[16];
-            sub[0] = nb == SH::OWN_BIT / 4 ? -sj - HSCALE * hq : 0; // the own bit's nibble carries the constants (own spin down)
+            uint32_t sub[16];
+            sub[0] = nb == SH::OWN_BIT / 4 ? 0u - sj - hs : 0u; // the own bit's nibble carries the constants (own spin down)
 #pragma unroll
             for (int n = 1; n < 16; n++) {
                 const int bit = 4 * nb + __builtin_ctz(n); // the index bit this pattern adds
-                const int32_t add = bit < SLOTS ? 2 * jq[bit < SLOTS ? bit : 0] : bit == SH::OWN_BIT ? 2 * HSCALE * hq : 0;
+                const uint32_t add = bit < SLOTS ? 2u * uint32_t(jq[bit < SLOTS ? bit : 0]) : bit == SH::OWN_BIT ? 2u * hs : 0u;
                 sub[n] = sub[n & (n - 1)] + add;
             }
 #pragma unroll
-            for (int n = 0; n < 16; n++) s_x[(16 * nb + n) * RjShape<SLOTS>::THREADS + tid] = uint32_t(sub[n]);
+            for (int n = 0; n < 16; n++) s_x[(16 * nb + n) * RjShape<SLOTS>::THREADS + tid] = sub[n];
         }
     }
 }
 
-// X (or the folded threshold operand) of the replica whose index is `idx` (16 bits: the low byte from the first transposition,
-// the high byte from the second)
+// X (or the folded threshold operand) of the replica whose index is `idx` (one byte per transposition, low byte first)
 template <int SLOTS>
 __device__ __forceinline__ uint32_t rj_lookup(const uint32_t *s_x, const uint32_t tid, const uint32_t idx)
 {
@@ -156,23 +158,18 @@ __device__ __forceinline__ void rj_gather_bias_only(const uint32_t *__restrict__
     w[RjShape<SLOTS>::OWN_BIT] = own;
 }
 
-// index words -> index bytes: w[b & 7] byte (b >> 3) = bits 0-7 of replica b's index, w[8 + (b & 7)] the same byte of bits 8-15
+// index words -> index bytes: w[8 G + (b & 7)] byte (b >> 3) = bits 8 G .. 8 G + 7 of replica b's index
 template <int SLOTS>
 __device__ __forceinline__ void rj_transpose_all(uint32_t (&w)[RjShape<SLOTS>::WORDS])
 {
-    uint32_t lo[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) lo[e] = w[e];
-    rj_transpose(lo);
+    for (int G = 0; G < RjShape<SLOTS>::WORDS / 8; G++) {
+        uint32_t x[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) w[e] = lo[e];
-    if constexpr (RjShape<SLOTS>::WORDS == 16) {
-        uint32_t hi[8];
+        for (int e = 0; e < 8; e++) x[e] = w[8 * G + e];
+        rj_transpose(x);
 #pragma unroll
-        for (int e = 0; e < 8; e++) hi[e] = w[8 + e];
-        rj_transpose(hi);
-#pragma unroll
-        for (int e = 0; e < 8; e++) w[8 + e] = hi[e];
+        for (int e = 0; e < 8; e++) w[8 * G + e] = x[e];
     }
 }
 
@@ -180,7 +177,8 @@ template <int SLOTS>
 __device__ __forceinline__ uint32_t rj_index(const uint32_t (&w)[RjShape<SLOTS>::WORDS], const int b)
 {
     uint32_t idx = (w[b & 7] >> (8 * (b >> 3))) & 0xFFu;
-    if constexpr (RjShape<SLOTS>::WORDS == 16) idx |= ((w[8 + (b & 7)] >> (8 * (b >> 3))) & 0xFFu) << 8;
+#pragma unroll
+    for (int G = 1; G < RjShape<SLOTS>::WORDS / 8; G++) idx |= ((w[8 * G + (b & 7)] >> (8 * (b >> 3))) & 0xFFu) << (8 * G);
     return idx;
 }
 
@@ -189,7 +187,9 @@ __device__ __forceinline__ uint32_t rj_index(const uint32_t (&w)[RjShape<SLOTS>:
 // group of a shard): only the Philox calls q_lo .. q_hi - 1 are drawn and only their replicas decided -- a replica's decisions
 // depend on nothing but its own spins, beta and bit position (S7), so the bits outside are nobody's business and stay as they are.
 // The cost of a position then is ~250 vector instructions + ~21 per decided replica instead of 932.
-template <int SLOTS, bool UB, bool PARTIAL = false>
+// HEAVY: the graph has sites that quantise at a coarser scale of their own (G.dshift; spec S7: X is shifted right by less, the
+// acceptance bound by the rest of d_p) -- one more shift per attempt; the PARTIAL instantiations always carry it.
+template <int SLOTS, bool UB, bool PARTIAL = false, bool HEAVY = PARTIAL>
 __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
                                                               const uint32_t real_end, const uint64_t t,
                                                               const uint2 *__restrict__ group_keys, const RjBeta *__restrict__ betas,
@@ -214,7 +214,16 @@ __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint3
         uint32_t own, w[RjShape<SLOTS>::WORDS];
         int32_t jq[SLOTS], hq;
         rj_gather<SLOTS>(st, G, p, own, jq, hq, w);
-        rj_build_tables<SLOTS, 1, FOLD>(s_x, tid, jq, hq, shift0);
+        // heavy site: X is in units of 2^(k + dsh); of those dsh binary places min(shift, dsh) come off the right shift of X, the
+        // rest off the bound (spec S7)
+        uint32_t dsh = 0, sx0 = shift0, sy0 = 0;
+        if constexpr (HEAVY) {
+            dsh = G.dshift ? uint32_t(G.dshift[p]) : 0u;
+            const uint32_t m = min(shift0, dsh);
+            sx0 = shift0 - m;
+            sy0 = dsh - m;
+        }
+        rj_build_tables<SLOTS, 1, FOLD>(s_x, tid, jq, hq, sx0);
         rj_transpose_all<SLOTS>(w);
         uint32_t flips = 0;
 #pragma unroll
@@ -228,9 +237,16 @@ __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint3
             for (int i = 0; i < 4; i++) {
                 const int b = 4 * j + i;
                 const uint32_t xv = rj_lookup<SLOTS>(s_x, tid, rj_index<SLOTS>(w, b));
-                const uint32_t shift = UB ? shift0 : gb[b].shift, mant = UB ? mant0 : gb[b].mant;
+                uint32_t shift = UB ? sx0 : gb[b].shift, sy = sy0;
+                const uint32_t mant = UB ? mant0 : gb[b].mant;
+                if constexpr (HEAVY && !UB) {
+                    const uint32_t m = min(shift, dsh);
+                    shift -= m;
+                    sy = dsh - m;
+                }
                 const uint32_t xpos = FOLD ? xv : uint32_t(max(int32_t(xv) >> shift, 0));
-                const uint32_t y = __umulhi(rj_lambda(u4[i], s_log), mant);
+                uint32_t y = __umulhi(rj_lambda(u4[i], s_log), mant);
+                if constexpr (HEAVY) y >>= sy;
                 flips |= uint32_t(xpos <= y) << b;
             }
         }
@@ -318,16 +334,17 @@ __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_measure_kernel(con
     }
 }
 
-// tempering on the stream: energies of the local slots from the measurement counters, E = 2^k (-c / 2) + self-loop constant
-// (the arithmetic of the host's pk_energy: the same bits); the counters are left zeroed for the next round
+// tempering on the stream: energies of the local slots from the two measurement counters of a slot (hi level, lo level: each
+// -2 x an exact integer sum), E = (2^kE hi + 2^(kE - 24) lo) + self-loop constant -- the arithmetic of the host's pk_energy: the
+// same bits; the counters are left as they are (the next measurement zeroes them)
 __attribute__((unused)) static __global__ void rj_energy_from_counts_kernel(unsigned long long *__restrict__ meas, const uint32_t first_slot,
-                                                                            const uint32_t n, const int k, const double self_energy,
+                                                                            const uint32_t n, const int k_energy, const double self_energy,
                                                                             double *__restrict__ out)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) {
-        const long long c = (long long)meas[2 * size_t(first_slot + r)];
-        out[r] = ldexp(double(-(c / 2)), k) + self_energy;
+        const long long hi = (long long)meas[2 * size_t(first_slot + r)], lo = (long long)meas[2 * size_t(first_slot + r) + 1];
+        out[r] = (ldexp(double(-(hi / 2)), k_energy) + ldexp(double(-(lo / 2)), k_energy - 24)) + self_energy;
     }
 }
 

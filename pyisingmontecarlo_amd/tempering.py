@@ -124,14 +124,15 @@ class ClassicalTempering:
         import os
         self._on_stream = (bool(getattr(self._engine, "supports_on_stream_pt", False)) and self._hi > self._lo and
                            os.environ.get("ISINGMC_PT_HOST", "0") in ("", "0"))  # ISINGMC_PT_HOST=1: the host swap step (A/B runs)
+        # eligibility first, WITHOUT side effects (e.g. a real-coupling graph too small for the packed kernels, a bit-sliced shard
+        # that cuts a replica group: the host swap step serves those) ...
         if self._on_stream:
-            try:
-                self._states.pt_attach(self._betas, self._lo, self._per, self._world, self._seed)
-            except ValueError:  # e.g. a real-coupling graph too small for the packed kernels: the host swap step serves it
-                self._on_stream = False
-        if self._world > 1:  # every rank must take the same path (the collective differs)
-            flags = D.all_gather_f64(np.array([float(self._on_stream)]), 1, self._group)
+            self._on_stream = self._states.pt_can_attach(G, self._lo, self._per, self._world)
+        if self._world > 1:  # ... then every rank must take the same path (the collective differs) ...
+            flags = D.all_gather_f64(np.array([float(self._on_stream)]), 1, self._group)  # (a rank without slots has no buffers to gather into: host path for all)
             self._on_stream = bool(flags.min() > 0)
+        if self._on_stream:  # ... and only then does anyone attach
+            self._states.pt_attach(self._betas, self._lo, self._per, self._world, self._seed)
         if self._on_stream:
             self._pt_local, self._pt_all = self._states.pt_buffers()
             self._pt_stream = self._states.pt_stream() if self._world > 1 else None

@@ -349,10 +349,12 @@ def test_packed_general_path_bit_exact(capi, oracle, exact, monkeypatch):
     st.set_state(33, other)                                                  # one replica of the second group
     got = st.states().astype(np.uint8)
     assert np.array_equal(got[33], other) and np.array_equal(got[32], s_ref[32]) and np.array_equal(got[34], s_ref[34])
-    # ClassicIsing.add_graph on a packed container (round 3): replica 35 joins the open group and takes over the chain bit 3 of
-    # group 1 has been running since the group was created
+    # ClassicIsing.add_graph on a packed container: replica 35 joins the open group and starts from the random start of its bit
+    # position (round 4; until round 3 it took over the chain bit 3 of group 1 had been running since the group was created)
     st.append(5)
-    assert st.count == 36 and np.array_equal(st.states().astype(np.uint8)[35], s_ref[35])
+    _, start0 = oracle.pk_run(ea3, eb3, ej3, n, capi.make_seeds(77, 36), 0, betas=[])
+    got = st.states().astype(np.uint8)
+    assert st.count == 36 and np.array_equal(got[35], start0[35]) and np.array_equal(got[34], s_ref[34])
 
 
 def _circulant(n, offsets, J):

@@ -24,7 +24,7 @@ def _random_graph(rng, n, m, maxdeg, skip=0):
 def _case(capi, oracle, ea, eb, ej, nvars, R, T, beta=None, beta_replica=None, biases=None, initial=None, slots=None):
     seeds = capi.make_seeds(77, R)
     g = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
-    assert g.kind == capi.KIND_GENERAL and g.info.real_slots == (slots or g.info.real_slots) and g.info.real_slots in (4, 7, 11, 15)
+    assert g.kind == capi.KIND_GENERAL and g.info.real_slots == (slots or g.info.real_slots) and g.info.real_slots in (4, 7, 11, 15, 23, 31)
     assert g.info.real_quantum_log2 == oracle.rj_quantise(ea, eb, ej, nvars, biases)[0]
     st = capi.States(g, seeds, initial_state=initial)
     ref_states = None if initial is None else np.tile(np.asarray(initial, dtype=np.uint8), (32 * ((R + 31) // 32), 1))
@@ -237,14 +237,12 @@ def test_classic_ising_on_the_packed_paths_and_append(oracle, exact, monkeypatch
         ci.run_monte_carlo(0.6, 2)
         _, ref = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 2, betas=[0.6] * 2)
         assert np.array_equal(ci.get_states(), ref[:31].astype(bool))
-        # replica 31 joins the open group.  Bit-sliced path: it takes over the chain bit 31 has been running since t = 0 (the
-        # unused replicas of a group are simulated: its tie numbering needs them).  Real-coupling path: bits a container does
-        # not own are not simulated, and the new replica starts from its random start now (t = 2), like on any other path.
+        # replica 31 joins the open group: it starts from the random start of its bit position now (t = 2), like a replica
+        # appended on any other path (round 4: on the bit-sliced path too, where the unused replicas of a group are simulated)
         ci.add_graph()
         seeds.append(int(oracle.make_seeds(42, 32)[-1]))
-        if run is oracle.rj_run:
-            _, start0 = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 0, betas=[])
-            ref[31] = start0[31]
+        _, start0 = run(ea, eb, ej, N, np.array(seeds, dtype=np.uint64), 0, betas=[])
+        ref[31] = start0[31]
         assert ci.get_num_graphs() == 32 and np.array_equal(ci.get_states()[31], ref[31].astype(bool))
         # replica 32 opens a new group, keyed by its seed, started now (t = 2); replica 33 comes with an explicit state
         ci.add_graph()

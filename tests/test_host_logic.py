@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(capi):
     for name in sorted(declared):
         assert hasattr(L, name), f"libisingmc.so does not export {name}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert L.isingmc_abi_version() == 3
+    assert L.isingmc_abi_version() == 4
 
 
 def test_no_cpu_fallback(capi, exact):

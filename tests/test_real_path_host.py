@@ -49,7 +49,7 @@ def test_lambda_is_minus_log2_to_2e_minus_7(oracle):
 
 def test_quantisation_and_beta_scales_match_oracle(capi, oracle):
     rng = np.random.default_rng(3)
-    for trial in range(20):
+    for trial in range(30):
         n = int(rng.integers(5, 60))
         ea, eb = _random_graph(rng, n, min(2 * n, n * (n - 1) // 2 - 1), 15)
         scale = 10.0 ** rng.integers(-6, 7)
@@ -59,26 +59,80 @@ def test_quantisation_and_beta_scales_match_oracle(capi, oracle):
             ea = np.concatenate([ea, [ea[0], 2]]).astype(np.uint64)
             eb = np.concatenate([eb, [eb[0], 2]]).astype(np.uint64)
             ej = np.concatenate([ej, [0.3 * scale, 1.5 * scale]])
-        k, jq, hq, ok = capi.rj_quantise(ea, eb, ej, n, h)
-        k2, jq2, hq2 = oracle.rj_quantise(ea, eb, ej, n, h)
+        if trial % 4 == 1 and h is not None:  # heavy sites: a pinning bias, and a site whose large terms could cancel
+            h[3] = 1e4 * scale
+            if trial % 8 == 1:
+                h[1] = -2e3 * scale
+        if trial % 7 == 2:
+            ej[0] = 5e5 * scale  # one enormous bond: both its ends are heavy and dominated by it
+        k, jq, hq, d, ok = capi.rj_quantise(ea, eb, ej, n, h)
+        k2, jq2, hq2, d2 = oracle.rj_quantise(ea, eb, ej, n, h)
         assert (k, ok) == (k2, oracle.rj_eligible(ea, eb, ej, n, h))
-        assert np.array_equal(jq, jq2) and np.array_equal(hq, hq2)
-        assert np.abs(jq).max() < 2 ** 30 + 8
-        np.testing.assert_allclose(jq * 2.0 ** k, np.where(ea == eb, 0.0, ej), atol=2.0 ** (k - 1))
+        assert np.array_equal(jq, jq2) and np.array_equal(hq, hq2) and np.array_equal(d, d2)
+        assert np.abs(jq).max() < 2 ** 30 + 8 and np.abs(hq).max() < 2 ** 30 + 8
+        if trial % 4 == 1 and h is not None or trial % 7 == 2:
+            assert d.max() > 0
+        # every site sees its bonds and its bias to half a quantum of its own scale 2^(k + d_i)
+        ia, ib = ea.astype(np.int64), eb.astype(np.int64)
+        bond = np.where(ea == eb, 0.0, ej)
+        np.testing.assert_array_less(np.abs(jq[:, 0] * 2.0 ** (k + d[ia].astype(int)) - bond), 2.0 ** (k + d[ia].astype(float) - 1) * (1 + 1e-12) + 1e-300)
+        np.testing.assert_array_less(np.abs(jq[:, 1] * 2.0 ** (k + d[ib].astype(int)) - bond), 2.0 ** (k + d[ib].astype(float) - 1) * (1 + 1e-12) + 1e-300)
+        # the two energy levels reproduce every term to Fmax 2^-54
+        kE, jhi, jlo, hhi, hlo = capi.rj_energy_levels(ea, eb, ej, n, h)
+        lev = oracle.rj_energy_levels(ea, eb, ej, n, h)
+        assert kE == lev[0] and all(np.array_equal(x, y) for x, y in zip((jhi, jlo, hhi, hlo), lev[1:]))
+        assert np.abs(jlo).max() <= 2 ** 23 and np.abs(jhi).max() < 2 ** 29 + 8
+        np.testing.assert_array_less(np.abs(jhi * 2.0 ** kE + jlo * 2.0 ** (kE - 24) - bond), 2.0 ** (kE - 25) * (1 + 1e-9) + 1e-300)
+        if h is not None:
+            np.testing.assert_array_less(np.abs(hhi * 2.0 ** kE + hlo * 2.0 ** (kE - 24) - h), 2.0 ** (kE - 25) * (1 + 1e-9) + 1e-300)
         for beta in (0.0, -1.0, 1e-12, 0.01, 0.4407, 1.0, 7.5, 1e9 / scale):
             assert capi.rj_beta(beta / scale, k) == oracle.rj_beta(beta / scale, k)
 
 
-def test_eligibility_bounds(capi):
+def test_eligibility_bounds(capi, oracle):
     ea, eb = np.array([0, 1, 2], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint64)
-    assert capi.rj_quantise(ea, eb, np.array([1.0, -0.5, 0.25]), 4)[3]
-    # one enormous bias: the common quantum would wipe out the other couplings -> not eligible (f64 CSR path)
-    assert not capi.rj_quantise(ea, eb, np.array([1.0, -0.5, 0.25]), 4, np.array([1e9, 0, 0, 0]))[3]
-    # degree 16 is one too many (four index nibbles hold 15 bonds + the own spin)
-    hub_a = np.zeros(16, dtype=np.uint64)
-    hub_b = np.arange(1, 17, dtype=np.uint64)
-    assert not capi.rj_quantise(hub_a, hub_b, np.ones(16) * 0.7, 17)[3]
-    assert capi.rj_quantise(hub_a[:15], hub_b[:15], np.ones(15) * 0.7, 16)[3]
+    j = np.array([1.0, -0.5, 0.25])
+    assert capi.rj_quantise(ea, eb, j, 4)[4]
+    # one enormous bias: the site quantises at its own coarse scale (it is dominated by that bias: no decision can hinge on the
+    # bits that scale drops), everything else keeps the graph's quantum (round 3: such graphs fell to the f64 CSR path)
+    k, jq, hq, d, ok = capi.rj_quantise(ea, eb, j, 4, np.array([1e9, 0, 0, 0]))
+    assert ok and d[0] > 0 and not d[1:].any() and k == capi.rj_quantise(ea, eb, j, 4)[0] + 5   # the quantum follows 64 x the median term
+    assert jq[0, 1] * 2.0 ** k == 1.0 and abs(hq[0] * 2.0 ** (k + int(d[0])) - 1e9) <= 2.0 ** (k + int(d[0]) - 1)
+    # a heavy site whose two large couplings can cancel each other is not dominated by one term: f64 CSR path
+    ca, cb = np.arange(9, dtype=np.uint64), np.arange(1, 10, dtype=np.uint64)       # a chain of ordinary bonds ...
+    big = np.ones(9)
+    big[3], big[4] = 1e6, -1e6 + 1                                                    # ... and site 4 between two enormous ones
+    assert not capi.rj_quantise(ca, cb, big, 10)[4] and not oracle.rj_eligible(ca, cb, big, 10)
+    big[4] = 1.0                                                                      # one enormous bond alone dominates both its ends
+    assert capi.rj_quantise(ca, cb, big, 10)[4] and oracle.rj_eligible(ca, cb, big, 10)
+    # degree 32 is one too many (eight index nibbles hold 31 bonds + the own spin)
+    hub_a = np.zeros(32, dtype=np.uint64)
+    hub_b = np.arange(1, 33, dtype=np.uint64)
+    assert not capi.rj_quantise(hub_a, hub_b, np.ones(32) * 0.7, 33)[4]
+    assert capi.rj_quantise(hub_a[:31], hub_b[:31], np.ones(31) * 0.7, 32)[4]
+
+
+def test_heavy_site_decisions_match_f64(oracle):
+    """A site pinned by a bias 10^6 x the couplings: at every beta from 1e-9 to 1e3 the integer test with the site's shift takes
+    the decision exp(-beta dE) dictates, up to the 2^-23 resolution of beta dE and the 2^-32 grain of the uniform."""
+    ea, eb = np.array([0, 1, 2], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint64)
+    j, h = np.array([1.0, -0.5, 0.25]), np.array([1e6, 0.0, 0.0, 0.0])
+    k, jq, hq, d, _ = oracle.rj_quantise(ea, eb, j, 4, h) + (None,)
+    X = int(hq[0]) - int(jq[0, 0])          # site 0 up, its neighbour up: dE = 2 (h - J) in units of 2^(k + d_0)
+    dE = 2.0 * X * 2.0 ** (k + int(d[0]))
+    rng = np.random.default_rng(4)
+    for beta in (1e-9, 1e-7, 3e-6, 1e-4, 0.01, 1.0, 1e3):
+        sh, mant = oracle.rj_beta(beta, k)
+        p = math.exp(-beta * dE)
+        us = np.concatenate([rng.integers(0, 2 ** 32, 2000, dtype=np.uint64), [0, 1, 2 ** 32 - 1]])
+        for u in us:
+            acc = oracle.rj_accept(X, int(u), sh, mant, int(d[0]))
+            uf = (int(u) + 0.5) / 2 ** 32
+            if uf < p * (1 - 1e-5) - 2.0 ** -31:
+                assert acc, (beta, u)
+            if uf > p * (1 + 1e-5) + 2.0 ** -31 and u != 0:
+                assert not acc, (beta, u)
+        assert oracle.rj_accept(-X, 12345, sh, mant, int(d[0]))   # towards the field: always
 
 
 def test_acceptance_probability_is_exp_to_1e_minus_7(oracle):
@@ -128,10 +182,11 @@ def test_engine_e_against_exact_enumeration_k2(oracle, exact):
         e_acc, m_acc = np.zeros(64), np.zeros(64)
         e, st, eps = oracle.rj_run(ea, eb, ej, n, seeds, T, betas=[beta] * T, biases=h, per_step=True)
         e_acc = eps[:, burn:].mean(axis=1)
-        # energies are those of the couplings rounded to 2^k: within (terms) x 2^(k-1) of the f64 energy
-        k = oracle.rj_quantise(ea, eb, ej, n, h)[0]
+        # energies are those of the ORIGINAL couplings (two integer levels): within (terms) x 2^(kE-25) + rounding of the f64 energy
+        kE = oracle.rj_energy_levels(ea, eb, ej, n, h)[0]
         for r in range(4):
-            assert abs(e[r] - oracle.energy(ea, eb, ej, n, st[r], h)) <= (len(ea) + n) * 2.0 ** (k - 1)
+            ref = oracle.energy(ea, eb, ej, n, st[r], h)
+            assert abs(e[r] - ref) <= (len(ea) + n) * 2.0 ** (kE - 25) + 8 * np.finfo(float).eps * (np.abs(ej).sum() + (0 if h is None else np.abs(h).sum()))
         # magnetisation: re-run in blocks to sample |M| (states only come out at the end of a call)
         m_samples = []
         t0, states = T, st  # (rj_run continues IN PLACE in the array it is handed)
