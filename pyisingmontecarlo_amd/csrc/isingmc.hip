@@ -1489,7 +1489,7 @@ static bool gen_resident_fits(const isingmc_graph *g, size_t n_replicas)
 static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real_path)
 {
     const uint64_t work = uint64_t(g->nvars) * n_replicas; // attempts per timestep
-    const bool csr_resident = gen_resident_fits(g, n_replicas) && !resident_disabled();
+    const bool csr_resident = gen_resident_fits(g, n_replicas); // (the A/B switch ISINGMC_DISABLE_RESIDENT changes kernels, never the family)
     if (real_path) {
         // partial groups draw only their own replicas' Philox calls: 1.09x the CSR launches at ONE experiment (2048^2 Gaussian glass,
         // profiles/r03_few_replicas.txt; re-measured in profiles/r04_real_eligibility.txt), 1.4x at 2, 2.0x at 4, 2.9x at 8

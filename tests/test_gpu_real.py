@@ -145,10 +145,10 @@ def test_one_biased_site_on_a_uniform_lattice_through_the_python_api(oracle, exa
     # few experiments: a partly used replica group (only the owned replicas' random numbers are drawn)
     e3, s3 = lat.run_monte_carlo(beta, T, 3)
     assert np.array_equal(e3, e_ref[:3]) and np.array_equal(s3, s_ref[:3].astype(bool))       # the same seeds: the same chains
-    # a single experiment runs on the f64 CSR path: a different (equally valid) chain
+    # a single experiment: the same family since round 4 (graphs beyond the LDS-resident CSR kernel take the real-coupling path
+    # from one experiment on), so experiment 0 is experiment 0 whatever the count (lattice.rs:83-91, 198)
     e1, s1 = lat.run_monte_carlo(beta, T, 1)
-    e1_ref = [oracle.gen_run(ea, eb, ej, W * H, int(sd), [beta] * T, biases=h)[0] for sd in lat.make_seeds(1)]
-    np.testing.assert_allclose(e1, e1_ref, rtol=1e-12)
+    assert np.array_equal(e1, e_ref[:1]) and np.array_equal(s1, s_ref[:1].astype(bool))
 
 
 def test_per_replica_betas_on_any_shard(capi, oracle, exact, monkeypatch):

@@ -194,28 +194,37 @@ def test_degrees_16_to_31(capi, oracle):
 
 def test_stable_path_makes_experiments_prefix_stable(capi, exact):
     """lattice.rs:83-91, 198: experiment k depends on seed k alone, so row 0 of run_monte_carlo(beta, T, 1) equals row 0 of
-    run_monte_carlo(beta, T, 40).  Here the kernel family normally follows the experiment count (f64 CSR kernels for one
-    experiment, replica-packed from 2 on: two different chains); with ISINGMC_FLAG_STABLE_PATH it follows the graph alone."""
-    W, H = 160, 128                                                         # 20 480 sites: too big for the LDS-resident CSR kernel
+    run_monte_carlo(beta, T, 512).  Here the kernel family follows the experiment count on SMALL graphs (the LDS-resident f64 CSR
+    kernel for few experiments, replica-packed for many: two different chains); with ISINGMC_FLAG_STABLE_PATH it follows the graph
+    alone.  Big graphs (beyond the resident kernel) take the packed family from ONE experiment on since round 4."""
+    W, H = 64, 64                                                           # 4 096 sites: the LDS-resident CSR kernel takes few experiments
     ea, eb, _ = exact.square_lattice_edges(W, H, 1.0)
     ej = np.random.default_rng(3).normal(size=len(ea))
     T, beta = 5, 0.8
-    seeds = capi.make_seeds(1, 40)
+    seeds = capi.make_seeds(1, 512)
     res = {}
     for stable in (True, False):
         g = capi.Graph(ea, eb, ej, nvars=W * H, stable_path=stable)
         assert g.info.stable_path == int(stable)
-        for R in (1, 2, 40):
+        for R in (1, 2, 512):
             st = capi.States(g, seeds[:R])
             st.do_time_steps(T, beta)
             res[stable, R] = (st.states(), st.energies())
     for R in (1, 2):
-        assert np.array_equal(res[True, R][0], res[True, 40][0][:R]) and np.array_equal(res[True, R][1], res[True, 40][1][:R])
-    assert np.array_equal(res[False, 2][0], res[False, 40][0][:2])        # both replica-packed
-    assert np.array_equal(res[True, 40][0], res[False, 40][0])            # the flag changes nothing where the packed family is chosen anyway
+        assert np.array_equal(res[True, R][0], res[True, 512][0][:R]) and np.array_equal(res[True, R][1], res[True, 512][1][:R])
+    assert np.array_equal(res[True, 512][0], res[False, 512][0])          # the flag changes nothing where the packed family is chosen anyway
+    assert np.array_equal(res[False, 1][0], res[False, 2][0][:1])         # both on the CSR kernels
     # without the flag ONE experiment runs on the f64 CSR kernels: another chain for the same Hamiltonian (documented, INTEGRATION 4)
-    assert not np.array_equal(res[False, 1][0][0], res[False, 40][0][0])
-    # uniform-|J| graphs (bit-sliced packed family): the same guarantee
+    assert not np.array_equal(res[False, 1][0][0], res[False, 512][0][0])
+    # a big graph: stable without the flag (real-coupling family from one experiment on)
+    Wb, Hb = 160, 128
+    eab, ebb, _ = exact.square_lattice_edges(Wb, Hb, 1.0)
+    gb = capi.Graph(eab, ebb, np.random.default_rng(4).normal(size=len(eab)), nvars=Wb * Hb)
+    one, many = capi.States(gb, seeds[:1]), capi.States(gb, seeds[:40])
+    one.do_time_steps(T, beta)
+    many.do_time_steps(T, beta)
+    assert np.array_equal(one.states()[0], many.states()[0]) and one.energies()[0] == many.energies()[0]
+    # uniform-|J| graphs (bit-sliced packed family): the same guarantee with the flag
     ea3, eb3, ej3 = exact.square_lattice_edges(96, 64, -1.0)
     g3 = capi.Graph(ea3, eb3, ej3, force_general=True, stable_path=True)
     a = capi.States(g3, seeds[:1]); a.do_time_steps(T, 0.4)
