@@ -84,6 +84,8 @@ typedef struct {
                               per term (two exact integer levels; = Fmax 2^-54) */
     int32_t real_heavy_sites;  /* sites that quantise at a coarser scale of their own (pinned by a large bias, ...) */
     int32_t stable_path;       /* 1 when created with ISINGMC_FLAG_STABLE_PATH */
+    int32_t packed_but_one_headers; /* one-degree packed kernel: (64-position block, slot) pairs that are one translation for every
+                              lane but one (a lattice row wrapping around inside the block) -- served without a table read */
 } isingmc_graph_info_t;
 
 const char *isingmc_last_error(void);
@@ -261,6 +263,22 @@ int isingmc_pt_state(isingmc_states *states, uint32_t *perm_out, uint64_t *round
 /* the engine's hipStream_t (for enqueuing the collective) and a host-side wait for it */
 int isingmc_states_stream(isingmc_states *states, void **stream_out);
 int isingmc_synchronize(isingmc_states *states);
+
+/* ---- in-process ladder across several devices --------------------------------------------------------------
+ * One host thread, one isingmc_states per device, each with the SAME ladder attached (isingmc_pt_attach with world_size =
+ * n_shards, slot_offset = k * slots_per_rank): the group runs the exchange step of tempering.rs:191-194 between them without any
+ * binding of the caller's to a collective library.  backend 0: RCCL (ncclCommInitAll + ncclAllGather on the engines' streams;
+ * librccl.so is loaded with dlopen when the group is created, so single-GPU users need nothing) when every shard has a device of
+ * its own and the library resolves, else event-ordered device copies (hipMemcpyPeerAsync); 1: RCCL or an error; 2: copies.
+ * isingmc_pt_group_run enqueues { timesteps; measure; all-gather; swap } for the whole ladder; nothing waits on the host until
+ * isingmc_pt_group_synchronize.  The shards stay the caller's (destroy the group first). */
+typedef struct isingmc_pt_group isingmc_pt_group;
+int isingmc_pt_group_create(isingmc_states **shards, size_t n_shards, int backend, isingmc_pt_group **group_out);
+int isingmc_pt_group_backend(const isingmc_pt_group *group); /* 1 = RCCL, 2 = device copies */
+int isingmc_pt_group_allgather(isingmc_pt_group *group);     /* enqueue only: local buffers -> every shard's all buffer */
+int isingmc_pt_group_run(isingmc_pt_group *group, size_t timesteps, size_t swap_every); /* enqueue only */
+int isingmc_pt_group_synchronize(isingmc_pt_group *group);
+void isingmc_pt_group_destroy(isingmc_pt_group *group);
 
 /* ---- measurement hook (bench.py; no reference counterpart) ------------------------------------------
  * Runs `timesteps` sweeps at `beta` like isingmc_do_time_steps and, beside them on a side stream, one

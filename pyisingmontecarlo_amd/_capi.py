@@ -21,7 +21,7 @@ class GraphInfo(C.Structure):
                 ("open_y", C.c_int32), ("field", C.c_double), ("jabs_y", C.c_double),
                 ("field_signs", C.c_int32), ("packed_degree", C.c_int32), ("real_slots", C.c_int32),
                 ("real_quantum_log2", C.c_int32), ("real_energy_log2", C.c_int32), ("real_heavy_sites", C.c_int32),
-                ("stable_path", C.c_int32)]
+                ("stable_path", C.c_int32), ("packed_but_one_headers", C.c_int32)]
 
 
 _vp = C.c_void_p
@@ -66,6 +66,12 @@ _PROTOTYPES = {
     "isingmc_pt_can_attach": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]),
     "isingmc_pt_detach": (C.c_int, [_vp]),
     "isingmc_pt_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "isingmc_pt_group_create": (C.c_int, [_vp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "isingmc_pt_group_backend": (C.c_int, [_vp]),
+    "isingmc_pt_group_allgather": (C.c_int, [_vp]),
+    "isingmc_pt_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t]),
+    "isingmc_pt_group_synchronize": (C.c_int, [_vp]),
+    "isingmc_pt_group_destroy": (None, [_vp]),
     "isingmc_pt_time_steps": (C.c_int, [_vp, C.c_size_t]),
     "isingmc_pt_measure": (C.c_int, [_vp]),
     "isingmc_pt_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t]),
@@ -132,6 +138,10 @@ def _check(rc):
     if rc == ERR_ALLOC:
         raise MemoryError(msg)
     raise RuntimeError(msg)
+
+
+def last_error():
+    return (lib().isingmc_last_error() or b"").decode()
 
 
 def _p(a):
@@ -222,6 +232,41 @@ def pt_swap_round(seed, rnd, betas, slot_energy, perm):
     _check(lib().isingmc_host_pt_swap_round(C.c_uint64(int(seed)), C.c_uint64(int(rnd)), len(betas), _p(betas),
                                             _p(slot_energy), _p(perm), C.byref(swaps)))
     return swaps.value
+
+
+class PtGroup:
+    """isingmc_pt_group: the shards of one ladder (States objects with the ladder attached, one per device) driven from this
+    thread; the energies travel by RCCL (dlopen'd inside the library) or by device copies.  backend: 0 auto, 1 RCCL, 2 copies."""
+
+    def __init__(self, shards, backend=0):
+        self.shards = list(shards)  # keeps them alive
+        self._h = _vp()
+        arr = (_vp * len(self.shards))(*[s._h for s in self.shards])
+        _check(lib().isingmc_pt_group_create(arr, len(self.shards), backend, C.byref(self._h)))
+
+    @property
+    def backend(self):
+        return {1: "rccl", 2: "copy"}[lib().isingmc_pt_group_backend(self._h)]
+
+    def allgather(self):
+        _check(lib().isingmc_pt_group_allgather(self._h))
+
+    def run(self, timesteps, swap_every):
+        _check(lib().isingmc_pt_group_run(self._h, timesteps, swap_every))
+
+    def synchronize(self):
+        _check(lib().isingmc_pt_group_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().isingmc_pt_group_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def release_cached_resources():

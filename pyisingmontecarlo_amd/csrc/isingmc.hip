@@ -334,7 +334,9 @@ struct isingmc_graph {
     int pk_uni_deg = 0;
     bool pk_uni_pmj = false;             // couplings of both signs
     PkUniHeaders pk_uni{};
+    uint32_t pk_uni_but_one = 0;         // (block, slot) headers that are a translation for every lane but one
     std::vector<uint32_t> pk_class_full; // per colour class: end of its last 256-block without padding
+    std::vector<uint8_t> pk_class_table; // per colour class: some block header of its full blocks is PK_HDR_MIXED (needs table entries)
     uint64_t n_directed = 0;
     // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 15
     bool rj_ok = false;
@@ -943,6 +945,7 @@ static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h, const d
 }
 
 static bool env_flag(const char *name);
+static int env_int(const char *name, int dflt);
 
 static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *eb, const double *ej,
                          size_t n_edges, size_t nvars, const double *biases)
@@ -1052,17 +1055,26 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
                 parallel_for(n_blocks, [&](size_t B) {
                     for (uint32_t i = 0; i < uint32_t(maxdeg); i++) {
                         const uint32_t *e = ell.data() + size_t(i) * n_pos + 64 * B;
-                        const uint32_t p0 = uint32_t(64 * B), delta = (e[0] & 0x7FFFFFFFu) - p0;
-                        bool translation = true;
+                        const uint32_t p0 = uint32_t(64 * B);
+                        const auto off = [&](uint32_t l) { return (e[l] & 0x7FFFFFFFu) - (p0 + l); };
+                        // the translation of the block: what two of its first three lanes agree on
+                        const uint32_t delta = off(1) == off(2) ? off(1) : off(0);
+                        uint32_t odd_lanes = 0, odd_lane = 0;
                         uint64_t mask = 0;
                         for (uint32_t l = 0; l < 64; l++) {
-                            translation &= e[l] != PK_NO_NBR && (e[l] & 0x7FFFFFFFu) - (p0 + l) == delta;
+                            if (e[l] == PK_NO_NBR || off(l) != delta) { odd_lanes++; odd_lane = l; }
                             mask |= uint64_t(e[l] != PK_NO_NBR && (e[l] >> 31)) << l;
                         }
-                        if (translation) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, delta);
+                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, delta);
+                        else if (odd_lanes == 1 && e[odd_lane] != PK_NO_NBR) { // a translation but for one lane (a row's wrap-around)
+                            const int32_t ex = int32_t(off(odd_lane) - delta);
+                            if (ex >= -(1 << 23) && ex < (1 << 23))
+                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), delta);
+                        }
                         sign[B * PK_MAX_DEG + i] = make_uint2(uint32_t(mask), uint32_t(mask >> 32));
                     }
                 });
+                for (const uint2 &hd : shift) g->pk_uni_but_one += (hd.x & 3u) == PK_HDR_UNIFORM_BUT_ONE && hd.x != PK_HDR_UNIFORM;
                 TRY(graph_upload(g, &g->pk_uni.shift, shift));
                 TRY(graph_upload(g, &g->pk_uni.sign, sign));
                 g->pk_class_full.resize(C.n_colours);
@@ -1071,6 +1083,10 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
                     while (uint32_t(C.class_base[c]) + real < uint32_t(C.class_base[c + 1]) && site[uint32_t(C.class_base[c]) + real] != PAD_SITE) real++;
                     g->pk_class_full[c] = uint32_t(C.class_base[c]) + real / 256 * 256;
                 }
+                g->pk_class_table.assign(C.n_colours, 0);
+                for (uint32_t c = 0; c < C.n_colours; c++)
+                    for (size_t B = C.class_base[c] / 64; B < g->pk_class_full[c] / 64 && !g->pk_class_table[c]; B++)
+                        for (uint32_t i = 0; i < uint32_t(maxdeg); i++) g->pk_class_table[c] |= (shift[B * PK_MAX_DEG + i].x & 3u) == PK_HDR_MIXED;
             }
         }
     }
@@ -1199,6 +1215,7 @@ extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *
     }
     info->n_colours = g->n_colours;
     info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
+    info->packed_but_one_headers = g->packed_ok ? int32_t(g->pk_uni_but_one) : 0;
     info->real_slots = g->rj_ok ? int32_t(g->rj.slots) : 0;
     info->real_quantum_log2 = g->rj_ok ? g->rj_k : 0;
     info->real_energy_log2 = g->rj_ok ? g->rj_k_energy : 0;
@@ -1528,6 +1545,9 @@ static void pk_fill_table(uint32_t *tab, double jabs, F &&beta_of)
                 if ((hi >> (N_PLANES - 1 - p)) & 1u) tab[PK_TAB_TBW + (m - 1) * N_PLANES + p] |= 1u << r;
             tab[PK_TAB_LO + (m - 1) * 32 + r] = uint32_t(T);
         }
+    // (meaningful when every replica has the same beta: the one-degree kernel's uniform-beta instantiation reads them)
+    for (uint32_t idx = 0; idx < uint32_t(PK_MAX_DEG) * N_PLANES; idx++)
+        if (tab[PK_TAB_TBW + idx] & 1u) tab[PK_TAB_SEL + (idx >> 5)] |= 1u << (idx & 31);
 }
 
 static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state)
@@ -1706,9 +1726,9 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
         for (size_t g0 = gb; g0 < ge; g0 += MAX_GRID_Y) {
             const size_t ng = std::min(MAX_GRID_Y, ge - g0);
             if (mid > b)
-                (void)pk_uni_launch_sweep(g->pk_uni_deg, tab_stride == 0, g->pk_uni_pmj, dim3((mid - b) / 1024 + ((mid - b) % 1024 != 0), unsigned(ng)),
-                                          stream, s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
-                                          tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride);
+                (void)pk_uni_launch_sweep(g->pk_uni_deg, tab_stride == 0, g->pk_uni_pmj, uint32_t(ng), stream,
+                                          s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
+                                          tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride, g->pk_class_table[c] != 0);
             if (e > mid)
                 hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - mid) / 1024 + ((e - mid) % 1024 != 0), unsigned(ng)), dim3(256), 0, stream,
                                    s->d_state + g0 * g->pk.n_pos, g->pk, mid, e, s->t, s->d_keys + g0,
@@ -3262,3 +3282,197 @@ extern "C" int isingmc_debug_shader_clock(isingmc_states *s, size_t timesteps, d
     *ghz_out = h_out[1] ? double(h_out[0]) / double(h_out[1]) * 0.1 : 0.0; // cycles per 10 ns tick -> GHz
     return ISINGMC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// In-process ladder across several devices: the shards of ONE beta ladder, each an isingmc_states on its
+// own device with the ladder attached (isingmc_pt_attach, world_size = the number of shards), driven from ONE host thread.
+// Between measure and swap every shard needs every shard's energies -- the swap step of tempering.rs:191-194 -- :
+//   * RCCL: ncclAllGather of the `local` buffers into the `all` buffers, one communicator per shard (ncclCommInitAll), enqueued on
+//     each shard's engine stream inside ncclGroupStart / ncclGroupEnd.  librccl.so is resolved with dlopen at group creation:
+//     a single-GPU user of libisingmc.so needs no RCCL at all, and a Rust / pyo3 host needs no NCCL binding of its own.
+//   * device copies (the shards share a device, RCCL is not installed, or ISINGMC_PT_GROUP_BACKEND=copy): the same gather as
+//     events + hipMemcpyPeerAsync on the engines' streams.
+// Both leave the same bytes in every `all` buffer; nothing in the loop waits on the host.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok() const { return handle && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+};
+constexpr int RCCL_FLOAT64 = 8; // ncclFloat64 (rccl.h)
+
+Rccl &rccl()
+{
+    static Rccl *r = [] {
+        auto *x = new Rccl;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            x->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x->handle) break;
+        }
+        if (x->handle) {
+            x->CommInitAll = reinterpret_cast<decltype(x->CommInitAll)>(dlsym(x->handle, "ncclCommInitAll"));
+            x->CommDestroy = reinterpret_cast<decltype(x->CommDestroy)>(dlsym(x->handle, "ncclCommDestroy"));
+            x->AllGather = reinterpret_cast<decltype(x->AllGather)>(dlsym(x->handle, "ncclAllGather"));
+            x->GroupStart = reinterpret_cast<decltype(x->GroupStart)>(dlsym(x->handle, "ncclGroupStart"));
+            x->GroupEnd = reinterpret_cast<decltype(x->GroupEnd)>(dlsym(x->handle, "ncclGroupEnd"));
+            x->GetErrorString = reinterpret_cast<decltype(x->GetErrorString)>(dlsym(x->handle, "ncclGetErrorString"));
+        }
+        return x;
+    }();
+    return *r;
+}
+} // namespace
+
+struct isingmc_pt_group {
+    std::vector<isingmc_states *> shards;
+    std::vector<void *> comms;        // RCCL communicators, one per shard (empty: device copies)
+    std::vector<hipEvent_t> measured; // per shard: its energies are in its `local` buffer
+    size_t per = 0;
+
+    ~isingmc_pt_group()
+    {
+        for (size_t k = 0; k < shards.size(); k++) {
+            (void)hipSetDevice(shards[k]->g->device);
+            (void)hipStreamSynchronize(shards[k]->stream);
+            if (k < comms.size() && comms[k]) (void)rccl().CommDestroy(comms[k]);
+            if (k < measured.size() && measured[k]) (void)hipEventDestroy(measured[k]);
+        }
+    }
+};
+
+static int rccl_fail(int rc, const char *what)
+{
+    const char *msg = rccl().GetErrorString ? rccl().GetErrorString(rc) : "?";
+    return fail(ISINGMC_ERR_HIP, std::string(what) + ": " + msg);
+}
+
+extern "C" int isingmc_pt_group_create(isingmc_states **shards, size_t n_shards, int backend, isingmc_pt_group **group_out)
+{
+    if (!shards || !group_out || n_shards == 0) return fail(ISINGMC_ERR_INVALID, "NULL argument / no shards");
+    *group_out = nullptr;
+    size_t offset = 0;
+    std::vector<int> devices;
+    bool distinct = true;
+    for (size_t k = 0; k < n_shards; k++) {
+        const isingmc_states *s = shards[k];
+        if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "every shard needs an attached ladder (isingmc_pt_attach)");
+        if (s->pt_world != n_shards || s->pt_per != shards[0]->pt_per || s->pt.n_rungs != shards[0]->pt.n_rungs ||
+            s->pt.seed_lo != shards[0]->pt.seed_lo || s->pt.seed_hi != shards[0]->pt.seed_hi)
+            return fail(ISINGMC_ERR_INVALID, "the shards are not attached to one ladder (world size, slots per rank, rungs, seed)");
+        if (s->pt.slot_offset != offset || s->pt.slot_offset != k * s->pt_per)
+            return fail(ISINGMC_ERR_INVALID, "shard k must own the slots from k * slots_per_rank on, in rank order");
+        offset += s->R;
+        for (int d : devices) distinct &= d != s->g->device;
+        devices.push_back(s->g->device);
+    }
+    if (offset != shards[0]->pt.n_rungs) return fail(ISINGMC_ERR_INVALID, "the shards do not cover the ladder");
+    auto grp = std::make_unique<isingmc_pt_group>();
+    grp->shards.assign(shards, shards + n_shards);
+    grp->per = shards[0]->pt_per;
+    grp->measured.assign(n_shards, nullptr);
+    for (size_t k = 0; k < n_shards; k++) {
+        TRY(use_device(devices[k]));
+        HIP_TRY(hipEventCreateWithFlags(&grp->measured[k], hipEventDisableTiming));
+    }
+    // backend: 0 = RCCL when the devices are distinct (or there is one shard) and librccl.so resolves, else device copies;
+    // 1 = RCCL or fail; 2 = device copies
+    const char *env = std::getenv("ISINGMC_PT_GROUP_BACKEND");
+    if (backend == 0 && env) backend = std::string(env) == "rccl" ? 1 : std::string(env) == "copy" ? 2 : 0;
+    const bool want_rccl = backend == 1 || (backend == 0 && distinct && rccl().ok());
+    if (backend == 1 && !rccl().ok()) return fail(ISINGMC_ERR_HIP, "librccl.so could not be loaded (dlopen)");
+    if (backend == 1 && !distinct) return fail(ISINGMC_ERR_INVALID, "RCCL needs one device per shard (ncclCommInitAll refuses duplicates)");
+    if (want_rccl) {
+        grp->comms.assign(n_shards, nullptr);
+        const int rc = rccl().CommInitAll(grp->comms.data(), int(n_shards), devices.data());
+        if (rc != 0) {
+            grp->comms.clear();
+            return rccl_fail(rc, "ncclCommInitAll");
+        }
+    }
+    *group_out = grp.release();
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_pt_group_backend(const isingmc_pt_group *grp)
+{
+    return grp && !grp->comms.empty() ? 1 : 2;
+}
+
+// enqueue: every shard's `local` energies -> every shard's `all` buffer (rank-major, slots_per_rank each)
+extern "C" int isingmc_pt_group_allgather(isingmc_pt_group *grp)
+{
+    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
+    const size_t n = grp->shards.size();
+    if (!grp->comms.empty()) {
+        int rc = rccl().GroupStart();
+        if (rc != 0) return rccl_fail(rc, "ncclGroupStart");
+        for (size_t k = 0; k < n && rc == 0; k++) {
+            isingmc_states *s = grp->shards[k];
+            rc = rccl().AllGather(s->d_pt_local, s->d_pt_all, grp->per, RCCL_FLOAT64, grp->comms[k], s->stream);
+        }
+        const int rc2 = rccl().GroupEnd();
+        if (rc != 0) return rccl_fail(rc, "ncclAllGather");
+        if (rc2 != 0) return rccl_fail(rc2, "ncclGroupEnd");
+        return ISINGMC_OK;
+    }
+    for (size_t j = 0; j < n; j++) { // shard j's measurement is complete ...
+        TRY(use_device(grp->shards[j]->g->device));
+        HIP_TRY(hipEventRecord(grp->measured[j], grp->shards[j]->stream));
+    }
+    for (size_t k = 0; k < n; k++) { // ... before any shard k copies it
+        isingmc_states *s = grp->shards[k];
+        TRY(use_device(s->g->device));
+        for (size_t j = 0; j < n; j++) {
+            const isingmc_states *src = grp->shards[j];
+            if (j != k) HIP_TRY(hipStreamWaitEvent(s->stream, grp->measured[j], 0));
+            HIP_TRY(hipMemcpyPeerAsync(s->d_pt_all + j * grp->per, s->g->device, src->d_pt_local, src->g->device, grp->per * sizeof(double), s->stream));
+        }
+    }
+    // a shard's `local` buffer is overwritten by its next measurement: that must wait for the copies the OTHER shards made of it
+    for (size_t k = 0; k < n; k++) {
+        TRY(use_device(grp->shards[k]->g->device));
+        HIP_TRY(hipEventRecord(grp->measured[k], grp->shards[k]->stream));
+    }
+    for (size_t j = 0; j < n; j++) {
+        TRY(use_device(grp->shards[j]->g->device));
+        for (size_t k = 0; k < n; k++)
+            if (k != j) HIP_TRY(hipStreamWaitEvent(grp->shards[j]->stream, grp->measured[k], 0));
+    }
+    return ISINGMC_OK;
+}
+
+// enqueue: the loop of tempering.rs:177-194 over the whole ladder -- `timesteps` sweeps on every shard with an exchange round
+// (measure, all-gather, swap) after every swap_every-th one
+extern "C" int isingmc_pt_group_run(isingmc_pt_group *grp, size_t timesteps, size_t swap_every)
+{
+    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
+    if (swap_every == 0) return fail(ISINGMC_ERR_INVALID, "swap_every must be positive");
+    for (size_t done = 0; done < timesteps;) {
+        const size_t b = std::min(swap_every, timesteps - done);
+        for (isingmc_states *s : grp->shards) TRY(isingmc_pt_time_steps(s, b));
+        done += b;
+        if (b == swap_every) {
+            for (isingmc_states *s : grp->shards) TRY(isingmc_pt_measure(s));
+            TRY(isingmc_pt_group_allgather(grp));
+            for (isingmc_states *s : grp->shards) TRY(isingmc_pt_swap(s));
+        }
+    }
+    return ISINGMC_OK;
+}
+
+extern "C" int isingmc_pt_group_synchronize(isingmc_pt_group *grp)
+{
+    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
+    for (isingmc_states *s : grp->shards) TRY(isingmc_synchronize(s));
+    return ISINGMC_OK;
+}
+
+extern "C" void isingmc_pt_group_destroy(isingmc_pt_group *grp) { delete grp; }

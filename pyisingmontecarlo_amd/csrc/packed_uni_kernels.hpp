@@ -77,49 +77,45 @@ __device__ __forceinline__ uint32_t pku_neg_of(const uint2 mask)
     return neg;
 }
 
-template <int D, bool UB, bool PMJ>
 #ifndef ISINGMC_PKU_WAVES
 #define ISINGMC_PKU_WAVES 8 // workgroups of 256 threads per CU the kernel is compiled for (A/B builds: 6 or 5 + ISINGMC_PKU_VKEYS)
 #endif
-__global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(uint32_t *__restrict__ state, const PkGraphDev G, const PkUniHeaders H,
-                                                               const uint32_t class_begin, const uint32_t class_end,
-                                                               const uint64_t t, const uint2 *__restrict__ group_keys,
-                                                               const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
-{
-    using CL = PkuClasses<D>;
-    constexpr int NJ = CL::NJ;
-    const uint32_t g = blockIdx.y;
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x; // wave w of the class owns positions [256w, 256w+256)
-    const uint32_t p0 = class_begin + 256 * (tid >> 6) + (tid & 63u); // the quad's leader
-    if (p0 >= class_end) return;
-    uint32_t *st = state + size_t(g) * G.n_pos;
-    const uint32_t *tab = tabs + size_t(g) * tab_stride;
-    const uint2 key = group_keys[g];
+#ifndef ISINGMC_PKU_PRE
+#define ISINGMC_PKU_PRE 0
+#endif
+
 #ifdef ISINGMC_PKU_VKEYS // A/B build: round keys 4-10 in vector registers (14 VGPRs; spills at the 64-VGPR cap of 8 waves)
-    const PhiloxVKeys vk = philox_vkeys(key);
 #define PKU_PHILOX(c) philox4x32_10(c, key, vk)
 #else
 #define PKU_PHILOX(c) philox4x32_10(c, key)
 #endif
 
-    const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
+// memory phase of the position-quad led by p0.  All 24 block headers first (scalar loads, one wait), then straight-line code: the
+// neighbour's position is own position + the header's shift; where a block is not a translation a branch holding nothing but a
+// load overwrites it with the table entry (a use of the loaded value inside the branch, or a header load per slot, makes the wave
+// wait for memory once per slot); then the gathers (the shift to a byte offset drops the sign bit).
+// (block headers, sign masks: read through the CONSTANT address space, so that the loads stay scalar inside the looping kernel
+//  too -- there the compiler cannot prove that the kernel's own stores leave them alone and would fall back to vector loads)
+typedef const __attribute__((address_space(4))) uint2 pku_const_uint2;
+__device__ __forceinline__ pku_const_uint2 *pku_const(const uint2 *p) { return (pku_const_uint2 *)(uintptr_t)p; }
 
-    // memory phase.  All 24 block headers first (scalar loads, one wait), then straight-line code: the neighbour's
-    // position is own position + the header's shift; where a block is not a translation a branch holding nothing but a
-    // load overwrites it with the table entry (a use of the loaded value inside the branch, or a header load per slot,
-    // makes the wave wait for memory once per slot); then the gathers (the shift to a byte offset drops the sign bit).
-    uint32_t own[4], ent[4][PK_MAX_DEG], nb[4][PK_MAX_DEG];
+// Neighbour positions of the position-quad led by p0 from its 24 block headers (scalar loads, one wait): own position + the
+// header's shift; + the exception of a block that is a translation for every lane but one; or -- anything else -- the table entry:
+// a branch holding NOTHING but the load (a use of the loaded value inside the branch, or a header load per slot, would make the wave
+// wait for memory once per slot; this way the first gather waits once for all of them, and for nothing on lattice-like graphs).
+// TABLE = false: the host has checked that no block of the launch needs its table entries (every (block, slot) is a translation,
+// for all lanes or for all but one): no load, no wait, nothing for the compiler to be careful about.
+template <int D, bool TABLE>
+__device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0,
+                                            const uint32_t lane, uint32_t (&ent)[4][PK_MAX_DEG])
+{
     uint2 h[4][PK_MAX_DEG];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint2 *hdr = H.shift + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
+        pku_const_uint2 *hdr = pku_const(H.shift) + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
 #pragma unroll
-        for (int i = 0; i < D; i++) h[q][i] = hdr[i];
+        for (int i = 0; i < D; i++) h[q][i] = make_uint2(hdr[i].x, hdr[i].y);
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -127,39 +123,58 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int i = 0; i < D; i++)
-            if (__builtin_amdgcn_readfirstlane(h[q][i].x) != PK_HDR_UNIFORM)
-                ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * G.n_pos + p0 + 64 * q), 0, 0);
+        for (int i = 0; i < D; i++) {
+            const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
+            if (hx != PK_HDR_UNIFORM) {
+                asm volatile(""); // (a real scalar branch, skipped by nearly every slot: if-converted, each slot pays ten instructions)
+                if (!TABLE || (hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? uint32_t(int32_t(hx) >> 8) : 0u;
+                else ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
+            }
+        }
+}
+
+// memory phase of the position-quad led by p0: neighbour positions, the gathers (the shift to a byte offset drops the sign bit of a
+// table entry), and the own words LAST -- the wait the compiler puts in front of the first gather (a table entry may be pending)
+// then finds nothing of ours in flight.
+template <int D, bool TABLE>
+__device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H,
+                                         const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
+                                         uint32_t (&nb)[4][PK_MAX_DEG])
+{
+    uint32_t ent[4][PK_MAX_DEG];
+    if constexpr (!TABLE) { // nothing to wait for before the gathers: the own words go first (they need no header)
+#pragma unroll
+        for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
+    }
+    pku_resolve<D, TABLE>(ell_rsrc, H, n_pos, p0, lane, ent);
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll
         for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, ent[q][i] << 2, 0, 0);
-
-    // The random words do not depend on the spins: the first ISINGMC_PKU_PRE planes are drawn here, between the issue of the
-    // gathers and the first use of their results, so that the memory round trip is covered by arithmetic of the wave's own
-    const uint32_t c0w = uint32_t(t), c1w = p0;
-#ifndef ISINGMC_PKU_PRE
-#define ISINGMC_PKU_PRE 0
-#endif
-    uint4 pre[ISINGMC_PKU_PRE > 0 ? ISINGMC_PKU_PRE : 1];
+    if constexpr (TABLE) {
 #pragma unroll
-    for (int k = 0; k < ISINGMC_PKU_PRE; k++) {
-        pre[k] = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES - 1 - k)));
-        asm volatile("" : "+v"(pre[k].x), "+v"(pre[k].y), "+v"(pre[k].z), "+v"(pre[k].w));
+        for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
     }
+}
 
-    // classes
-    uint32_t eq[4][3], lt[4], und[4], sure[4]; // sure: flips whatever the random numbers say
+// classes of the position-quad led by p0 from its own and neighbour words: eq[q][j] = the replicas with k_j satisfied bonds,
+// sure = flips whatever the random numbers say, und = costly and not yet decided
+template <int D, bool PMJ>
+__device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_t p0, const uint32_t *__restrict__ tab, const uint32_t (&own)[4],
+                                            const uint32_t (&nb)[4][PK_MAX_DEG], uint32_t (&eq)[4][3], uint32_t (&sure)[4], uint32_t (&und)[4])
+{
+    using CL = PkuClasses<D>;
+    constexpr int NJ = CL::NJ;
     uint32_t all_j[3];
 #pragma unroll
     for (int j = 0; j < NJ; j++) all_j[j] = tab[PK_TAB_ALL + CL::row(j)];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t sat[PK_MAX_DEG], c0, c1, c2;
-        const uint2 *signs = H.sign + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG;
+        pku_const_uint2 *signs = pku_const(H.sign) + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG;
 #pragma unroll
         for (int i = 0; i < D; i++) // J > 0: satisfied when the spins differ
-            sat[i] = pku_xor3(own[q], nb[q][i], PMJ ? pku_neg_of(signs[i]) : H.negmask);
+            sat[i] = pku_xor3(own[q], nb[q][i], PMJ ? pku_neg_of(make_uint2(signs[i].x, signs[i].y)) : H.negmask);
         pku_count<D>(sat, c0, c1, c2);
         eq[q][0] = pku_match<CL::k(0)>(c0, c1, c2);
         eq[q][1] = pku_match<CL::k(1)>(c0, c1, c2);
@@ -170,18 +185,49 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
         const uint32_t costly = NJ > 2 ? __builtin_amdgcn_bitop3_b32(eq[q][0], eq[q][1], eq[q][2], 0xFE) : eq[q][0] | eq[q][1];
         sure[q] = ~costly | allm;
         und[q] = costly & ~allm;
-        lt[q] = 0;
     }
+}
 
+// the random half: bit-planes of the acceptance uniform against the classes' thresholds, then the ties; acc[q] = the replica bits that flip
+template <int D, bool UB>
+__device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, const uint2 key,
+#ifdef ISINGMC_PKU_VKEYS
+                                           const PhiloxVKeys &vk,
+#endif
+                                           const uint32_t *__restrict__ tab, const uint32_t (&eq)[4][3], const uint32_t (&sure)[4],
+                                           uint32_t (&und)[4], uint32_t (&acc)[4])
+{
+    using CL = PkuClasses<D>;
+    constexpr int NJ = CL::NJ;
+    // The random words do not depend on the spins: the first ISINGMC_PKU_PRE planes are drawn here, between the issue of the
+    // gathers and the first use of their results, so that the memory round trip is covered by arithmetic of the wave's own
+    const uint32_t c0w = uint32_t(t), c1w = p0;
+    uint4 pre[ISINGMC_PKU_PRE > 0 ? ISINGMC_PKU_PRE : 1];
+#pragma unroll
+    for (int k = 0; k < ISINGMC_PKU_PRE; k++) {
+        pre[k] = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES - 1 - k)));
+        asm volatile("" : "+v"(pre[k].x), "+v"(pre[k].y), "+v"(pre[k].z), "+v"(pre[k].w));
+    }
+    uint32_t lt[4] = {0, 0, 0, 0};
+    uint32_t selw[2] = {0, 0}; // UB: which classes' threshold bits are set in each plane, from two table words (not 21 loads)
+    if constexpr (UB) { selw[0] = tab[PK_TAB_SEL]; selw[1] = tab[PK_TAB_SEL + 1]; }
     // bit-planes, least significant first: lt' = (~r & tb) | (~(r ^ tb) & lt), und' = und & ~(r ^ tb)
 #pragma unroll
     for (int pl = N_PLANES - 1; pl >= 0; pl--) {
         const uint4 rnd = N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? pre[N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? N_PLANES - 1 - pl : 0]
                                                               : PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)));
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-        uint32_t T[3];
+        uint32_t T[3] = {0, 0, 0};
+        if constexpr (UB) { // bit row * N_PLANES + pl of the two selection words: is this plane's bit of the row's threshold set?
 #pragma unroll
-        for (int j = 0; j < NJ; j++) T[j] = tab[PK_TAB_TBW + CL::row(j) * N_PLANES + pl];
+            for (int j = 0; j < NJ; j++) {
+                const int idx = CL::row(j) * N_PLANES + pl;
+                T[j] = 0u - ((selw[idx >> 5] >> (idx & 31)) & 1u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) T[j] = tab[PK_TAB_TBW + CL::row(j) * N_PLANES + pl];
+        }
         if constexpr (UB) {
             // every T_j is 0 or ~0: one scalar branch selects the classes whose threshold has this bit set
             const uint32_t sel = __builtin_amdgcn_readfirstlane((T[0] & 1u) | (T[1] & 2u) | (NJ > 2 ? (T[2] & 4u) : 0u));
@@ -221,7 +267,6 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
         }
     }
 
-    uint32_t acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = sure[q] | lt[q];
     if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
@@ -249,9 +294,58 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
             }
         }
     }
+}
+
+
+// decisions of the position-quad led by p0 from its own and neighbour words; acc[q] = the replica bits that flip
+template <int D, bool UB, bool PMJ>
+__device__ __forceinline__ void pku_decide(const PkUniHeaders &H, const uint32_t p0, const uint64_t t, const uint2 key,
+#ifdef ISINGMC_PKU_VKEYS
+                                           const PhiloxVKeys &vk,
+#endif
+                                           const uint32_t *__restrict__ tab, const uint32_t (&own)[4], const uint32_t (&nb)[4][PK_MAX_DEG],
+                                           uint32_t (&acc)[4])
+{
+    uint32_t eq[4][3], sure[4], und[4];
+    pku_classes<D, PMJ>(H, p0, tab, own, nb, eq, sure, und);
+#ifdef ISINGMC_PKU_VKEYS
+    pku_random<D, UB>(p0, t, key, vk, tab, eq, sure, und, acc);
+#else
+    pku_random<D, UB>(p0, t, key, tab, eq, sure, und, acc);
+#endif
+}
+
+template <int D, bool UB, bool PMJ, bool TABLE>
+__global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(uint32_t *__restrict__ state, const PkGraphDev G, const PkUniHeaders H,
+                                                               const uint32_t class_begin, const uint32_t class_end,
+                                                               const uint64_t t, const uint2 *__restrict__ group_keys,
+                                                               const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
+{
+    const uint32_t g = blockIdx.y;
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x; // wave w of the class owns positions [256 w, 256 w + 256)
+    const uint32_t p0 = class_begin + 256 * (tid >> 6) + (tid & 63u); // the quad's leader
+    if (p0 >= class_end) return;
+    uint32_t *st = state + size_t(g) * G.n_pos;
+    const uint32_t *tab = tabs + size_t(g) * tab_stride;
+    const uint2 key = group_keys[g];
+#ifdef ISINGMC_PKU_VKEYS
+    const PhiloxVKeys vk = philox_vkeys(key);
+#define PKU_VK vk,
+#else
+#define PKU_VK
+#endif
+    const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
+
+    uint32_t own[4], nb[4][PK_MAX_DEG], acc[4];
+    pku_load<D, TABLE>(st_rsrc, ell_rsrc, H, G.n_pos, p0, tid & 63u, own, nb);
+    pku_decide<D, UB, PMJ>(H, p0, t, key, PKU_VK tab, own, nb, acc);
 #pragma unroll
     for (int q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(own[q] ^ acc[q], st_rsrc, 4 * (p0 + 64 * q), 0, 0);
-#undef PKU_PHILOX
+#undef PKU_VK
 }
+
+#undef PKU_PHILOX
 
 } // namespace isingmc

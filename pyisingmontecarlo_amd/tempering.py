@@ -3,7 +3,9 @@ LatticeTempering (src/tempering.rs:29-299; quantum SSE there -- the classical la
 own): add_graph(beta), timesteps(t), timesteps_sample(timesteps, replica_swap_freq,
 sampling_freq) -> (bool[G,S,N] states, float64[G] time-averaged energies), get_total_swaps().
 
-Replica slots are sharded over the ranks of a torch.distributed group (one process per GPU).  The swap
+Replica slots are sharded over the ranks of a torch.distributed group (one process per GPU) -- or, with
+`devices=[...]`, over several GPUs driven by THIS process through the library's own RCCL group
+(isingmc_pt_group_*: no torch, no launcher; what a Rust / pyo3 host of the C ABI would use).  The swap
 step exchanges TEMPERATURES, never configurations: every rank all-gathers one float64 energy per slot
 (RCCL over xGMI with backend nccl), evaluates the same Philox-keyed decisions in libisingmc's host code
 (isingmc_host_pt_swap_round) and re-labels its own slots' betas.  No spin ever crosses a link.
@@ -49,8 +51,16 @@ def _split(edges):
 
 
 class ClassicalTempering:
-    def __init__(self, edges, seed=None, *, group=None, device=None, engine_factory=None):
+    def __init__(self, edges, seed=None, *, group=None, device=None, engine_factory=None, devices=None, group_backend=0):
+        """devices: HIP ordinals of an IN-PROCESS ladder -- shard k of the slots lives on devices[k] and the exchange step runs
+        through the library's RCCL group (group_backend 0: RCCL when the devices are distinct, else device copies; 1: RCCL;
+        2: copies).  Mutually exclusive with a torch.distributed `group`."""
         self._ea, self._eb, self._ej = _split(edges)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        self._group_backend = int(group_backend)
+        self._shards, self._pgroup = None, None
+        if self._devices is not None and (group is not None or D.world_rank(group)[0] > 1):
+            raise ValueError("devices=[...] is the in-process ladder: not inside a torch.distributed job")
         self.nvars = int(max(self._ea.max(), self._eb.max())) + 1  # tempering.rs:44-49
         self._group = group
         self._world, self._rank = D.world_rank(group)
@@ -95,6 +105,8 @@ class ClassicalTempering:
         return len(self._betas)
 
     def get_total_swaps(self):  # tempering.rs:297-299
+        if self._pgroup is not None:
+            return int(self._shards[0].pt_state()[2])
         if self._on_stream:
             return int(self._states.pt_state()[2]) if self._hi > self._lo else self._total_swaps
         return self._total_swaps
@@ -105,7 +117,9 @@ class ClassicalTempering:
     def get_permutation(self):
         """rung -> replica slot currently holding that temperature."""
         self._materialise()
-        if self._on_stream and self._hi > self._lo:
+        if self._pgroup is not None:
+            self._perm = self._shards[0].pt_state()[0]
+        elif self._on_stream and self._hi > self._lo:
             self._perm = self._states.pt_state()[0]
         return self._perm.copy()
 
@@ -116,6 +130,8 @@ class ClassicalTempering:
         G = len(self._betas)
         if G == 0:
             raise ValueError("no graphs: call add_graph(beta) first")
+        if self._devices is not None:
+            return self._materialise_in_process(G)
         self._per = D.block_size(G, self._world)
         self._lo, self._hi = D.shard_bounds(G, self._world, self._rank)
         self._engine = self._engine_factory()
@@ -138,6 +154,45 @@ class ClassicalTempering:
             self._pt_stream = self._states.pt_stream() if self._world > 1 else None
         else:
             self._push_betas()
+
+    def _materialise_in_process(self, G):
+        """One shard per device, the same ladder attached to each, an isingmc_pt_group between them."""
+        n = len(self._devices)
+        if n == 0:
+            raise ValueError("devices must name at least one GPU")
+        self._per = D.block_size(G, n)
+        seeds = np.array(self._slot_seeds, dtype=np.uint64)
+        self._bounds = [D.shard_bounds(G, n, k) for k in range(n)]
+        if any(hi <= lo for lo, hi in self._bounds):
+            raise ValueError("more devices than blocks of rungs: every device needs at least one slot")
+        shards = []
+        for k, dev in enumerate(self._devices):
+            engine = HipEngine(self._ea, self._eb, self._ej, self.nvars, device=dev)
+            st = engine.make_states(seeds, self._bounds[k])
+            if not (engine.supports_on_stream_pt and st.pt_can_attach(G, self._bounds[k][0], self._per, n)):
+                raise ValueError("the in-process ladder needs on-stream tempering on every shard (a periodic field-free lattice or "
+                                 "a replica-packed graph; on the bit-sliced path shards of whole 32-slot groups): " + _capi.last_error())
+            shards.append(st)
+        for k, st in enumerate(shards):
+            st.pt_attach(self._betas, self._bounds[k][0], self._per, n, self._seed)
+        self._shards = shards
+        self._pgroup = _capi.PtGroup(shards, self._group_backend)
+        self._states = shards[0]
+        self._lo, self._hi = 0, G
+        self._perm = np.arange(G, dtype=np.uint32)
+        self._on_stream = True
+
+    def group_backend(self):
+        """'rccl' or 'copy' for an in-process ladder (devices=[...]), else None."""
+        self._materialise()
+        return None if self._pgroup is None else self._pgroup.backend
+
+    def _in_process_swap_round(self):
+        for st in self._shards:
+            st.pt_measure()
+        self._pgroup.allgather()
+        for st in self._shards:
+            st.pt_swap()
 
     def _push_betas(self):
         G = len(self._betas)
@@ -191,6 +246,14 @@ class ClassicalTempering:
         self._materialise()
         if t <= 0:
             return
+        if self._pgroup is not None:
+            if not replica_swap_freq:
+                for st in self._shards:
+                    st.pt_time_steps(int(t))
+            else:
+                self._pgroup.run(int(t), int(replica_swap_freq))
+            self._pgroup.synchronize()
+            return
         if not replica_swap_freq:
             if self._hi > self._lo:
                 self._states.do_time_steps(t)
@@ -223,6 +286,8 @@ class ClassicalTempering:
         held at each sample (configurations never leave their GPU).
         """
         self._materialise()
+        if self._pgroup is not None:
+            return self._timesteps_sample_in_process(timesteps, replica_swap_freq, sampling_freq)
         if self._on_stream and self._hi > self._lo:
             self._perm = self._states.pt_state()[0]  # the device owns the ladder state
         sampling_freq = 1 if sampling_freq is None else int(sampling_freq)
@@ -265,3 +330,43 @@ class ClassicalTempering:
                 by_rung[rungs[:, s], s, :] = states[:, s, :]
             return by_rung, energies
         return states, energies, rungs
+
+    def _timesteps_sample_in_process(self, timesteps, replica_swap_freq, sampling_freq):
+        """The countdown scheduler of tempering.rs:156-222 over the shards of an in-process ladder: (states bool[G, S, N] by
+        rung, energies float64[G])."""
+        sampling_freq = 1 if sampling_freq is None else int(sampling_freq)
+        replica_swap_freq = 1 if replica_swap_freq is None else int(replica_swap_freq)
+        if sampling_freq <= 0:
+            raise ValueError("sampling_freq must be positive")
+        G, N = len(self._betas), self.nvars
+        S = timesteps // sampling_freq
+        perm = self._shards[0].pt_state()[0]
+        states = np.zeros((G, S, N), dtype=np.bool_)           # by slot first
+        rungs = np.zeros((G, S), dtype=np.int64)
+        energy_acc = np.zeros(G, dtype=np.float64)
+        remaining, to_swap, to_sample, k = timesteps, replica_swap_freq, sampling_freq, 0
+        while remaining > 0:
+            t = min(to_sample, remaining) if replica_swap_freq <= 0 else min(to_sample, to_swap, remaining)
+            slot_sum = np.concatenate([st.do_time_steps(t, per_step_energies=True).sum(axis=1) for st in self._shards])
+            energy_acc += slot_sum[perm]                         # energy_acc[rung] += te * t (tempering.rs:185)
+            to_sample -= t
+            to_swap -= t
+            remaining -= t
+            if to_swap == 0 and replica_swap_freq > 0:
+                self._in_process_swap_round()
+                perm = self._shards[0].pt_state()[0]
+                to_swap = replica_swap_freq
+            if to_sample == 0:
+                if k < S:
+                    for (lo, hi), st in zip(self._bounds, self._shards):
+                        st.states(out=states[lo:hi, k, :])
+                    inv = np.empty(G, dtype=np.int64)
+                    inv[perm] = np.arange(G)
+                    rungs[:, k] = inv
+                k += 1
+                to_sample = sampling_freq
+        self._perm = perm
+        by_rung = np.empty_like(states)
+        for s in range(S):
+            by_rung[rungs[:, s], s, :] = states[:, s, :]
+        return by_rung, energy_acc / max(timesteps, 1)

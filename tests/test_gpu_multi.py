@@ -113,3 +113,60 @@ def test_rccl_collective_on_the_engine_stream_single_rank(tmp_path):
     assert subprocess.call([sys.executable, os.path.join(ROOT, "tests", "_nccl_world1_worker.py"), out], env=env, timeout=600) == 0
     res = json.load(open(out))
     assert res["perm_equal"] and res["states_equal"] and res["rounds"] == 10 and res["swaps"] == res["swaps_ref"] > 0
+
+
+def _ladder_results(pt, T, swap, S_T, S_swap, S_freq):
+    pt.timesteps(T, swap)
+    perm = pt.get_permutation().tolist()
+    swaps = pt.get_total_swaps()
+    states, energies = pt.timesteps_sample(S_T, S_swap, S_freq)[:2]
+    return perm, swaps, states, energies, pt.get_permutation().tolist(), pt.get_total_swaps()
+
+
+@pytest.mark.parametrize("kind", ["lattice_strips", "real_glass"])
+def test_in_process_ladder_equals_the_single_device_ladder(kind):
+    """ClassicalTempering(edges, devices=[...]) -- the library's own group (isingmc_pt_group_*) between the
+    shards, no torch.distributed, no launcher.  With both shards on this box's one GPU the energies travel by event-ordered
+    device copies (RCCL refuses duplicate devices); with ONE shard the group builds a real RCCL communicator (librccl.so resolved
+    with dlopen inside libisingmc.so, world size 1) and the all-gather runs on the engine's stream.  Each must reproduce the
+    plain single-container ladder bit for bit: permutation, swap count, sampled configurations, time-averaged energies."""
+    from oracle import exact as X
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    if kind == "lattice_strips":
+        ea, eb, ej = X.square_lattice_edges(1024, 256, -1.0)       # strip geometry: the sweeps of a round are one persistent launch
+        G, betas = 8, np.linspace(0.40, 0.47, 8)
+    else:
+        ea, eb, _ = X.square_lattice_edges(160, 128, 1.0)            # a Gaussian glass: replica-packed real-coupling containers
+        ej = np.random.default_rng(2).normal(size=len(ea))
+        G, betas = 40, np.linspace(0.3, 1.6, 40)
+    runs = {}
+    for name, kw in (("solo", {}), ("two_shards_copy", dict(devices=[0, 0])), ("one_shard_rccl", dict(devices=[0], group_backend=1))):
+        pt = ClassicalTempering((ea, eb, ej), 11, **kw)
+        for b in betas:
+            pt.add_graph(float(b))
+        runs[name] = _ladder_results(pt, 30, 5, 12, 4, 6)
+        if kw:
+            assert pt.group_backend() == ("rccl" if name.endswith("rccl") else "copy")
+    ref = runs["solo"]
+    assert ref[1] > 0 and ref[5] > ref[1]
+    for name in ("two_shards_copy", "one_shard_rccl"):
+        got = runs[name]
+        assert got[0] == ref[0] and got[1] == ref[1] and got[4] == ref[4] and got[5] == ref[5], name
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), name
+
+
+def test_in_process_ladder_over_rccl_two_gpus():
+    """The same with a device per shard (needs two GPUs): ncclCommInitAll + grouped ncclAllGather inside the library."""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs: RCCL between two devices of one process")
+    from oracle import exact as X
+    from pyisingmontecarlo_amd.tempering import ClassicalTempering
+    ea, eb, ej = X.square_lattice_edges(1024, 256, -1.0)
+    betas = np.linspace(0.40, 0.47, 8)
+    runs = []
+    for kw in ({}, dict(devices=[0, 1], group_backend=1)):
+        pt = ClassicalTempering((ea, eb, ej), 11, **kw)
+        for b in betas:
+            pt.add_graph(float(b))
+        runs.append(_ladder_results(pt, 30, 5, 12, 4, 6))
+    assert runs[1][0] == runs[0][0] and runs[1][1] == runs[0][1] > 0 and np.array_equal(runs[1][2], runs[0][2])

@@ -357,6 +357,26 @@ def test_packed_general_path_bit_exact(capi, oracle, exact, monkeypatch):
     assert st.count == 36 and np.array_equal(got[35], start0[35]) and np.array_equal(got[34], s_ref[34])
 
 
+def test_packed_one_degree_kernel_serves_row_wraparounds_without_the_table(capi, oracle, exact):
+    """A lattice row of 128 positions per colour wraps around inside every second 64-position block: the one-degree kernel's
+    headers describe such a block as 'a translation for every lane but one' (round 4) instead of sending the wave to the ELL
+    table -- and a class all of whose headers are translations takes the instantiation without table reads at all.  256 x 64
+    (degree 4) and 256 x 8 x 8 (degree 6) against engine D, ferromagnet and +-J, uniform and per-replica betas."""
+    ea, eb, ej = exact.square_lattice_edges(256, 64, -1.0)
+    g = capi.Graph(ea, eb, ej, force_general=True)
+    assert g.info.packed_degree == 4 and g.info.packed_but_one_headers > 0
+    _packed_case(capi, oracle, ea, eb, ej, 256 * 64, R=40, T=4, beta=0.5)
+    _packed_case(capi, oracle, ea, eb, ej, 256 * 64, R=64, T=3, beta_replica=np.linspace(0.1, 0.9, 64))
+    ea2, eb2, ej2 = exact.square_lattice_edges(256, 64, 1.0, np.random.default_rng(12))
+    _packed_case(capi, oracle, ea2, eb2, ej2, 256 * 64, R=33, T=4, beta=0.8)
+    ids = np.arange(256 * 8 * 8, dtype=np.uint64).reshape(8, 8, 256)       # 256 x 8 x 8 cubic: degree 6, x rows of 128 per colour
+    ea3 = np.concatenate([ids.ravel()] * 3)
+    eb3 = np.concatenate([np.roll(ids, -1, axis=a).ravel() for a in (2, 1, 0)])
+    g3 = capi.Graph(ea3, eb3, np.full(len(ea3), -1.0), force_general=True)
+    assert g3.info.packed_degree == 6 and g3.info.packed_but_one_headers > 0
+    _packed_case(capi, oracle, ea3, eb3, np.full(len(ea3), -1.0), 256 * 64, R=40, T=3, beta=0.25)
+
+
 def _circulant(n, offsets, J):
     """Site i bonded to i + d (mod n) for d in offsets; d == n/2 gives one bond per pair: every site has the same degree."""
     ea, eb = [], []
