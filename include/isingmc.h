@@ -186,6 +186,11 @@ int isingmc_states_append(isingmc_states *states, uint64_t seed, const uint8_t *
 int isingmc_states_set_state(isingmc_states *states, size_t replica, const uint8_t *state);
 size_t isingmc_states_count(const isingmc_states *states);
 void isingmc_states_destroy(isingmc_states *states);
+/* One of the path / tuning switches of THIS container: `name` is the environment variable's name without the ISINGMC_ prefix
+ * (e.g. "strip", "disable_resident", "pk_streams", "sample_slab_bytes"; case-insensitive).  Every switch is read from the
+ * environment once, when a graph / a container is created -- never at call time -- so two containers of one process can differ.
+ * The kernel FAMILY (force_real, disable_real, force_packed, disable_packed) is fixed at creation and cannot be changed here. */
+int isingmc_states_set_option(isingmc_states *states, const char *name, long value);
 
 /* Per-replica inverse temperatures (parallel-tempering ladder; shaped after
  * LatticeTempering.add_graph(beta), tempering.rs:70-113).  NULL clears them.  While set, the

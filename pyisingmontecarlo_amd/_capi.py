@@ -1,6 +1,7 @@
 """ctypes binding of include/isingmc.h (libisingmc.so).  No fallback of any kind: if the HIP library
 is missing or no device is usable, calls raise."""
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -52,6 +53,7 @@ _PROTOTYPES = {
     "isingmc_states_set_state": (C.c_int, [_vp, C.c_size_t, _vp]),
     "isingmc_states_count": (C.c_size_t, [_vp]),
     "isingmc_states_destroy": (None, [_vp]),
+    "isingmc_states_set_option": (C.c_int, [_vp, C.c_char_p, C.c_long]),
     "isingmc_states_set_betas": (C.c_int, [_vp, _vp]),
     "isingmc_do_time_steps": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "isingmc_do_time_steps_timed": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_float)]),
@@ -243,6 +245,8 @@ class PtGroup:
         self._h = _vp()
         arr = (_vp * len(self.shards))(*[s._h for s in self.shards])
         _check(lib().isingmc_pt_group_create(arr, len(self.shards), backend, C.byref(self._h)))
+        for s in self.shards:  # a shard that is closed (or finalised by the cycle collector, in any order) closes its groups first
+            s._groups.append(self)
 
     @property
     def backend(self):
@@ -286,6 +290,7 @@ class Graph:
         _check(lib().isingmc_graph_create(_p(ea), _p(eb), _p(ej), len(ea), nvars, _p(biases), device,
                                           (FLAG_FORCE_GENERAL if force_general else 0) | (FLAG_STABLE_PATH if stable_path else 0),
                                           C.byref(self._h)))
+        self._children = []
         info = GraphInfo()
         _check(lib().isingmc_graph_info(self._h, C.byref(info)))
         self.info = info
@@ -295,6 +300,10 @@ class Graph:
 
     def close(self):
         if self._h:
+            for ref in getattr(self, "_children", []):  # replica containers hold a pointer to the graph: they go first, whatever
+                child = ref()                           # order the garbage collector finalises a reference cycle in
+                if child is not None:
+                    child.close()
             lib().isingmc_graph_destroy(self._h)
             self._h = _vp()
 
@@ -312,6 +321,7 @@ class States:
         """seeds: one u64 per experiment.  replica_range=(lo, hi): this object is the shard [lo, hi) of the
         len(seeds) experiments (isingmc_states_create_range: results do not depend on the cut)."""
         self.graph = graph  # keeps the graph alive
+        self._groups = []
         self._h = _vp()
         seeds = _arr(seeds, np.uint64)
         ini = _arr(initial_state, np.uint8)
@@ -325,6 +335,7 @@ class States:
                 raise ValueError("replica_range out of bounds")
             _check(lib().isingmc_states_create_range(graph._h, len(seeds), _p(seeds), lo, hi - lo, _p(ini),
                                                      C.byref(self._h)))
+        graph._children.append(weakref.ref(self))
 
     @property
     def count(self):
@@ -347,6 +358,10 @@ class States:
         if st.size != self.graph.nvars:
             raise ValueError("Initial state must be of the same size as biases, or 0.")
         _check(lib().isingmc_states_set_state(self._h, replica, _p(st)))
+
+    def set_option(self, name, value):
+        """One of the path / tuning switches of this container (the ISINGMC_* variable's name without the prefix)."""
+        _check(lib().isingmc_states_set_option(self._h, name.encode(), int(value)))
 
     def set_betas(self, betas):
         b = _arr(betas, np.float64)
@@ -477,6 +492,8 @@ class States:
 
     def close(self):
         if self._h:
+            for grp in getattr(self, "_groups", []):
+                grp.close()
             lib().isingmc_states_destroy(self._h)
             self._h = _vp()
 

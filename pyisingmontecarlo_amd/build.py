@@ -15,8 +15,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libisingmc.so")
 EXT = os.path.join(HERE, "_py_monte_carlo" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
-HIP_SOURCES = ["isingmc.hip", "strip_kernels.hip", "spread_kernels.hip", "mc_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip", "host_logic.cpp"]
-HIP_DEPS = HIP_SOURCES + ["philox.hpp", "lattice_kernels.hpp", "strip_kernels.hpp", "strip_types.hpp", "spread_kernels.hpp", "spread_types.hpp", "mc_kernels.hpp", "mc_quad_body.inc", "mc_types.hpp", "general_kernels.hpp", "packed_kernels.hpp", "packed_types.hpp", "packed_uni_kernels.hpp", "real_kernels.hpp", "real_types.hpp", "host_logic.hpp",
+HIP_SOURCES = ["core.hip", "graph.hip", "isingmc.hip", "sampling.hip", "tempering.hip", "debug.hip", "strip_kernels.hip", "spread_kernels.hip", "mc_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip", "host_logic.cpp"]
+HIP_DEPS = HIP_SOURCES + ["internal.hpp", "philox.hpp", "lattice_kernels.hpp", "strip_kernels.hpp", "strip_types.hpp", "spread_kernels.hpp", "spread_types.hpp", "mc_kernels.hpp", "mc_quad_body.inc", "mc_types.hpp", "general_kernels.hpp", "packed_kernels.hpp", "packed_types.hpp", "packed_uni_kernels.hpp", "real_kernels.hpp", "real_types.hpp", "host_logic.hpp",
                           os.path.join(ROOT, "include", "isingmc.h")]
 EXT_SOURCES = ["py_monte_carlo.cpp"]
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gen_sweep_kernel(
 }
 
 // random start: packed word w = Philox(key, (0, w>>2, 0, "GENI"))[w&3], padding bits cleared
-__global__ __launch_bounds__(256) void gen_init_kernel(uint32_t *__restrict__ state,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void gen_init_kernel(uint32_t *__restrict__ state,
                                                        const GenGraphDev G,
                                                        const uint2 *__restrict__ keys,
                                                        const uint32_t first_replica)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gen_measure_kernel(const uint32_t *__rest
 }
 
 // fixed-order tree sum of one replica's partials: out_e[r], out_m[r]
-__global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restrict__ partial_e,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void gen_reduce_kernel(const double *__restrict__ partial_e,
                                                          const long long *__restrict__ partial_m,
                                                          const uint32_t n_partials,
                                                          double *__restrict__ out_e,
@@ -375,7 +375,7 @@ struct PtDev {
     uint32_t seed_lo, seed_hi;
 };
 
-__global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *__restrict__ thr_local /*thr_words words per local slot*/,
+__attribute__((unused)) static __global__ __launch_bounds__(1024) void pt_swap_kernel(const PtDev P, uint64_t *__restrict__ thr_local /*thr_words words per local slot*/,
                                                        double *__restrict__ beta_local, const uint32_t apply_only)
 {
     const unsigned long long round = P.counters[0];

@@ -1,1231 +1,8 @@
-// libisingmc.so: the C ABI of include/isingmc.h over the HIP kernels (gfx950 only).
-// Host orchestration only -- every Monte-Carlo operation runs in the kernels of
-// lattice_kernels.hpp / general_kernels.hpp.  There is no CPU fallback.
-#include <hip/hip_runtime.h>
-#include <sys/mman.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/isingmc.h"
-#include "general_kernels.hpp"
-#include "host_logic.hpp"
-#include "lattice_kernels.hpp"
-#include "packed_kernels.hpp"
-#include "mc_types.hpp"
-#include "real_types.hpp"
-#include "spread_types.hpp"
-#include "strip_types.hpp"
-
-using namespace isingmc;
-
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-
-static int fail(int code, const std::string &msg)
-{
-    g_last_error = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t err__ = (expr);                                                                 \
-        if (err__ != hipSuccess)                                                                   \
-            return fail(err__ == hipErrorOutOfMemory ? ISINGMC_ERR_ALLOC : ISINGMC_ERR_HIP,        \
-                        std::string(#expr) + ": " + hipGetErrorString(err__));                     \
-    } while (0)
-
-#define TRY(expr)                                                                                  \
-    do {                                                                                           \
-        int rc__ = (expr);                                                                         \
-        if (rc__ != ISINGMC_OK) return rc__;                                                       \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// handles
-// ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------
-// Device blocks are recycled: a call of the reference's API creates its replicas, runs and drops them again
-// (Lattice.run_monte_carlo, lattice.rs:171-221), and for a small lattice hipMalloc / hipFree -- each a device-wide
-// synchronisation -- cost more than the timesteps: 2.1 ms of a 2.2 ms call of ONE timestep on 16 x 16 x 4 (tools/small_call_overhead.py).
-// Freed blocks of up to 64 MiB wait in a per-device list (at most 512 MiB / 256 blocks) for the next request of exactly their
-// size.  Every owner synchronises its streams before it frees (hipFree did that implicitly).  ISINGMC_NO_ALLOC_CACHE=1: off.
-// ------------------------------------------------------------------------------------------------
-namespace {
-struct DevCache {
-    std::mutex mu;
-    std::unordered_map<void *, std::pair<int, size_t>> live;        // block -> (device, bytes)
-    std::multimap<std::pair<int, size_t>, void *> idle;             // (device, bytes) -> block
-    size_t idle_bytes = 0;
-    static constexpr size_t MAX_BLOCK = size_t(64) << 20, MAX_IDLE = size_t(512) << 20, MAX_COUNT = 256;
-};
-DevCache &dev_cache()
-{
-    static DevCache *c = new DevCache; // never destroyed: the HIP runtime may be gone by the time static destructors run
-    return *c;
-}
-bool dev_cache_off()
-{
-    static const bool off = [] { const char *e = std::getenv("ISINGMC_NO_ALLOC_CACHE"); return e && *e && *e != '0'; }();
-    return off;
-}
-} // namespace
-
-static hipError_t cached_malloc(void **out, size_t bytes)
-{
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return err;
-    DevCache &c = dev_cache();
-    if (!dev_cache_off()) {
-        std::lock_guard<std::mutex> lock(c.mu);
-        auto it = c.idle.find({dev, bytes});
-        if (it != c.idle.end()) {
-            *out = it->second;
-            c.idle.erase(it);
-            c.idle_bytes -= bytes;
-            c.live[*out] = {dev, bytes};
-            return hipSuccess;
-        }
-    }
-    err = hipMalloc(out, bytes);
-    if (err != hipSuccess && !dev_cache_off()) { // out of memory: give the idle blocks back and try once more
-        std::vector<void *> drop;
-        {
-            std::lock_guard<std::mutex> lock(c.mu);
-            for (auto &kv : c.idle) drop.push_back(kv.second);
-            c.idle.clear();
-            c.idle_bytes = 0;
-        }
-        for (void *p : drop) (void)hipFree(p);
-        (void)hipGetLastError();
-        err = hipMalloc(out, bytes);
-    }
-    if (err == hipSuccess && !dev_cache_off()) {
-        std::lock_guard<std::mutex> lock(c.mu);
-        c.live[*out] = {dev, bytes};
-    }
-    return err;
-}
-
-static hipError_t cached_free(void *p)
-{
-    if (!p) return hipSuccess;
-    DevCache &c = dev_cache();
-    {
-        std::lock_guard<std::mutex> lock(c.mu);
-        auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            const auto key = it->second;
-            c.live.erase(it);
-            if (!dev_cache_off() && key.second <= DevCache::MAX_BLOCK && c.idle_bytes + key.second <= DevCache::MAX_IDLE &&
-                c.idle.size() < DevCache::MAX_COUNT) {
-                c.idle.emplace(key, p);
-                c.idle_bytes += key.second;
-                return hipSuccess;
-            }
-        }
-    }
-    return hipFree(p);
-}
-
-// ... and pinned host blocks (the staging buffers of get_states / the sampling pipeline: pinning and unpinning cost ~150 us each)
-namespace {
-struct HostCache {
-    std::mutex mu;
-    std::unordered_map<void *, size_t> live;
-    std::multimap<size_t, void *> idle;
-    size_t idle_bytes = 0;
-};
-HostCache &host_cache()
-{
-    static HostCache *c = new HostCache;
-    return *c;
-}
-} // namespace
-
-static hipError_t cached_host_malloc(void **out, size_t bytes)
-{
-    HostCache &c = host_cache();
-    if (!dev_cache_off()) {
-        std::lock_guard<std::mutex> lock(c.mu);
-        auto it = c.idle.find(bytes);
-        if (it != c.idle.end()) {
-            *out = it->second;
-            c.idle.erase(it);
-            c.idle_bytes -= bytes;
-            c.live[*out] = bytes;
-            return hipSuccess;
-        }
-    }
-    const hipError_t err = hipHostMalloc(out, bytes, hipHostMallocDefault);
-    if (err == hipSuccess && !dev_cache_off()) {
-        std::lock_guard<std::mutex> lock(c.mu);
-        c.live[*out] = bytes;
-    }
-    return err;
-}
-
-static hipError_t cached_host_free(void *p)
-{
-    if (!p) return hipSuccess;
-    HostCache &c = host_cache();
-    {
-        std::lock_guard<std::mutex> lock(c.mu);
-        auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            const size_t bytes = it->second;
-            c.live.erase(it);
-            if (!dev_cache_off() && bytes <= (size_t(64) << 20) && c.idle_bytes + bytes <= (size_t(256) << 20) && c.idle.size() < 64) {
-                c.idle.emplace(bytes, p);
-                c.idle_bytes += bytes;
-                return hipSuccess;
-            }
-        }
-    }
-    return hipHostFree(p);
-}
-
-// Streams are recycled the same way (creating and destroying the three streams of a replica container took ~1.5 ms of that
-// call): non-blocking streams per device, handed back idle (their owner synchronises them first).
-namespace {
-struct StreamPool {
-    std::mutex mu;
-    std::multimap<int, hipStream_t> idle; // device -> stream
-};
-StreamPool &stream_pool()
-{
-    static StreamPool *p = new StreamPool;
-    return *p;
-}
-} // namespace
-
-static hipError_t pooled_stream_create(hipStream_t *out)
-{
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return err;
-    if (!dev_cache_off()) {
-        StreamPool &p = stream_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        auto it = p.idle.find(dev);
-        if (it != p.idle.end()) {
-            *out = it->second;
-            p.idle.erase(it);
-            return hipSuccess;
-        }
-    }
-    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
-
-// hipStreamSynchronize costs ~70 us even on an idle stream; a query is enough when everything has completed
-static hipError_t stream_quiesce(hipStream_t st)
-{
-    if (hipStreamQuery(st) == hipSuccess) return hipSuccess;
-    (void)hipGetLastError(); // hipErrorNotReady is not an error
-    return hipStreamSynchronize(st);
-}
-
-static void pooled_stream_destroy(hipStream_t st)
-{
-    if (!st) return;
-    int dev = 0;
-    if (!dev_cache_off() && stream_quiesce(st) == hipSuccess && hipGetDevice(&dev) == hipSuccess) {
-        StreamPool &p = stream_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        if (p.idle.size() < 64) {
-            p.idle.emplace(dev, st);
-            return;
-        }
-    }
-    (void)hipStreamDestroy(st);
-}
-
-// ... and events (two kinds: with timing for the *_timed entry point, without for ordering between streams)
-namespace {
-struct EventPool {
-    std::mutex mu;
-    std::multimap<std::pair<int, bool>, hipEvent_t> idle; // (device, timing disabled?) -> event
-};
-EventPool &event_pool()
-{
-    static EventPool *p = new EventPool;
-    return *p;
-}
-} // namespace
-
-static hipError_t pooled_event_create(hipEvent_t *out, bool disable_timing)
-{
-    int dev = 0;
-    if (!dev_cache_off() && hipGetDevice(&dev) == hipSuccess) {
-        EventPool &p = event_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        auto it = p.idle.find({dev, disable_timing});
-        if (it != p.idle.end()) {
-            *out = it->second;
-            p.idle.erase(it);
-            return hipSuccess;
-        }
-    }
-    return disable_timing ? hipEventCreateWithFlags(out, hipEventDisableTiming) : hipEventCreate(out);
-}
-
-// (called with the owner's device current, as the destructors and creators here are)
-static void pooled_event_destroy(hipEvent_t ev, bool disable_timing)
-{
-    if (!ev) return;
-    int dev = 0;
-    if (!dev_cache_off() && hipGetDevice(&dev) == hipSuccess) {
-        EventPool &p = event_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        if (p.idle.size() < 256) {
-            p.idle.emplace(std::make_pair(dev, disable_timing), ev);
-            return;
-        }
-    }
-    (void)hipEventDestroy(ev);
-}
-
-struct isingmc_graph {
-    int device = 0;
-    int kind = ISINGMC_KIND_GENERAL;
-    uint64_t nvars = 0, n_edges = 0;
-    uint64_t state_words = 0;
-    bool has_bias = false;
-    // lattice path
-    LatGeom geom{};
-    bool vec = false;
-    double jabs = 0.0;
-    bool uniform_sign = true;
-    uint32_t jneg_uniform = 0;
-    uint32_t *d_jneg = nullptr; // [2 colours][4 directions][wpp]
-    // multi-class checkerboard kernels (mc_types.hpp): uniform field or open boundaries on a recognised lattice
-    int mc_mode = MC_NONE;
-    double jabs_y = 0.0;  // MC_ANISO: |J| of the vertical bonds (jabs = the horizontal ones')
-    double field = 0.0;   // MC_FIELD: h of E = sum J s s - h sum s
-    McOpen open{0, 0, 0}; // MC_OPEN, MC_FIELD_OPEN
-    uint32_t *d_fneg = nullptr; // fields of one size and both signs: sign planes [2][wpp] (bit set where h_i < 0); field = |h| then
-    // general path
-    GenGraphDev gdev{};
-    uint32_t gen_edges2 = 0; // directed edges of the CSR (rowptr[n_pos])
-    bool w_is_float = false;
-    std::vector<uint64_t> class_base;
-    std::vector<uint64_t> pos; // site -> packed position
-    double self_energy = 0.0;
-    uint32_t n_colours = 2;
-    // replica-packed variant of the general path (uniform |J|, no fields, degree <= PK_MAX_DEG)
-    bool packed_ok = false;
-    PkGraphDev pk{};
-    // every real site has this degree (3..6): packed_uni_kernels.hpp; 0 otherwise
-    int pk_uni_deg = 0;
-    bool pk_uni_pmj = false;             // couplings of both signs
-    PkUniHeaders pk_uni{};
-    uint32_t pk_uni_but_one = 0;         // (block, slot) headers that are a translation for every lane but one
-    std::vector<uint32_t> pk_class_full; // per colour class: end of its last 256-block without padding
-    std::vector<uint8_t> pk_class_table; // per colour class: some block header of its full blocks is PK_HDR_MIXED (needs table entries)
-    uint64_t n_directed = 0;
-    // replica-packed real-coupling path (real_kernels.hpp): any couplings and biases, degree <= 15
-    bool rj_ok = false;
-    RjGraphDev rj{};                      // the dynamics' view
-    RjGraphDev rj_hi{}, rj_lo{};          // the same topology with the two integer levels of the ORIGINAL couplings (energies)
-    int rj_k = 0;                         // the dynamics' couplings are integers in units of 2^rj_k (heavy sites: 2^(rj_k + dshift))
-    int rj_k_energy = 0;                  // energy = 2^rj_k_energy S(hi) + 2^(rj_k_energy - 24) S(lo)
-    uint32_t rj_heavy_sites = 0;
-    bool stable_path = false;             // ISINGMC_FLAG_STABLE_PATH: the kernel family never depends on the number of experiments
-    std::vector<uint32_t> class_real_end; // per colour class: end of its real sites (the padding follows)
-    std::vector<void *> dev_allocs;
-
-    ~isingmc_graph()
-    {
-        (void)hipSetDevice(device);
-        (void)hipDeviceSynchronize(); // the blocks are recycled (cached_free): no kernel may still be reading the graph
-        for (void *p : dev_allocs) (void)cached_free(p);
-    }
-};
-
-struct isingmc_states {
-    isingmc_graph *g = nullptr;
-    size_t R = 0, cap = 0;
-    uint32_t *d_state = nullptr;
-    uint2 *d_keys = nullptr;
-    uint64_t t = 0; // absolute timestep = Philox counter
-    hipStream_t stream = nullptr;
-    std::vector<hipStream_t> lanes; // sweep launches of disjoint replica blocks alternate over these (see run_steps)
-    std::vector<hipEvent_t> lane_events;
-    hipEvent_t fork_event = nullptr;
-    size_t n_lanes = 1; // lanes in use by the current run_steps call
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool has_betas = false;
-    std::vector<double> betas;
-    LatThr *d_thr = nullptr;
-    LatThrMC *d_thr_mc = nullptr; // per-replica thresholds of the multi-class kernels (has_betas on a field / open lattice)
-    double *d_beta = nullptr;
-    // measurement scratch
-    unsigned long long *d_meas = nullptr; // lattice: [R][2]
-    bool meas_zero = false;               // d_meas is known to be all zero (left so by the tempering measurement)
-    double *d_pe = nullptr, *d_oe = nullptr;
-    long long *d_pm = nullptr, *d_om = nullptr;
-    uint32_t n_partials = 0;
-    // replica-packed general path: one word per position = 32 replicas of a group
-    bool packed = false;
-    size_t groups = 0;
-    size_t pk_bit0 = 0; // replica r of this shard is bit (r + pk_bit0) % 32 of group (r + pk_bit0) / 32 (shards cut GLOBAL groups)
-    size_t pk_slots() const { return 32 * groups; } // counter slots: one per (group, bit), owned or not
-    uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
-    bool rj = false;           // packed container on the real-coupling path (real_kernels.hpp) instead of the bit-sliced one
-    RjBeta *d_rj_betas = nullptr; // per-replica acceptance scales [32 groups] (has_betas)
-    unsigned long long *d_pk_slot_thr = nullptr; // on-stream tempering on the bit-sliced packed path: T_m per slot [32 groups][PK_MAX_DEG]
-    size_t n_total = 0, first = 0; // this container is the shard [first, first + R) of n_total experiments
-    // persistent strip kernel (strip_kernels.hpp): halo granules, error word, tag epoch
-    unsigned long long *d_halo = nullptr;
-    size_t halo_cap = 0; // granules allocated
-    uint32_t *d_strip_err = nullptr;
-    uint32_t strip_epoch = 0;
-    unsigned long long *d_pt_mail = nullptr, *d_pt_round_counts = nullptr; // in-kernel exchange rounds (StripLadder)
-    uint32_t *d_pt_perm2 = nullptr;
-    unsigned long long *d_strip_fin = nullptr; // [cap] final-measurement counters of the strip kernel (zero between launches)
-    bool strip_test_failed = false; // ISINGMC_STRIP_TEST_FAIL_ONCE has fired for this object
-    bool strip_disabled = false;    // a strip launch of this object timed out once: the per-colour launches serve it from then on
-    uint32_t *d_snapshot = nullptr; // the planes a synchronous call started from (restored when a strip launch gives up)
-    size_t snapshot_cap = 0;
-    bool meas_fresh = false; // the tempering send buffer holds the energies of the CURRENT configurations (written by the last strip launch)
-    // sampling pipeline (isingmc_run_sampling): two slabs of samples in flight
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t sample_ready[2] = {nullptr, nullptr}, sample_copied[2] = {nullptr, nullptr};
-    uint32_t *d_samples[2] = {nullptr, nullptr}, *h_samples[2] = {nullptr, nullptr}; // h_*: pinned
-    unsigned long long *d_sample_counts[2] = {nullptr, nullptr}, *h_counts[2] = {nullptr, nullptr};
-    double *d_sample_e[2] = {nullptr, nullptr}, *h_e[2] = {nullptr, nullptr};
-    long long *d_sample_m = nullptr;
-    size_t sample_cap_words = 0, sample_cap_counts = 0, sample_cap_e = 0;
-    // on-stream parallel tempering (isingmc_pt_*)
-    bool pt_attached = false;
-    PtDev pt{};
-    double *d_pt_ladder = nullptr, *d_pt_local = nullptr, *d_pt_all = nullptr;
-    uint64_t *d_pt_ladder_thr = nullptr;
-    uint32_t *d_pt_perm = nullptr;
-    unsigned long long *d_pt_counters = nullptr;
-    size_t pt_per = 0, pt_world = 1;
-
-    ~isingmc_states()
-    {
-        if (!g) return;
-        (void)hipSetDevice(g->device);
-        // the blocks below go back to the cache, where the next request may pick them up at once: nothing of this object may
-        // still be running (hipFree used to wait for the whole device)
-        if (stream) (void)stream_quiesce(stream);
-        for (auto st : lanes) (void)stream_quiesce(st);
-        if (copy_stream) (void)stream_quiesce(copy_stream);
-        for (void *p : {(void *)d_state, (void *)d_keys, (void *)d_thr, (void *)d_beta, (void *)d_meas,
-                        (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
-            if (p) (void)cached_free(p);
-        if (d_tab) (void)cached_free(d_tab);
-        if (d_rj_betas) (void)cached_free(d_rj_betas);
-        if (d_pk_slot_thr) (void)cached_free(d_pk_slot_thr);
-        if (d_thr_mc) (void)cached_free(d_thr_mc);
-        for (int b = 0; b < 2; b++) {
-            for (void *p : {(void *)d_samples[b], (void *)d_sample_counts[b], (void *)d_sample_e[b]})
-                if (p) (void)cached_free(p);
-            for (void *p : {(void *)h_samples[b], (void *)h_counts[b], (void *)h_e[b]})
-                if (p) (void)cached_host_free(p);
-            pooled_event_destroy(sample_ready[b], true);
-            pooled_event_destroy(sample_copied[b], true);
-        }
-        if (d_sample_m) (void)cached_free(d_sample_m);
-        pooled_stream_destroy(copy_stream);
-        if (d_halo) (void)cached_free(d_halo);
-        if (d_strip_err) (void)cached_free(d_strip_err);
-        if (d_strip_fin) (void)cached_free(d_strip_fin);
-        if (d_snapshot) (void)cached_free(d_snapshot);
-        for (void *p : {(void *)d_pt_mail, (void *)d_pt_round_counts, (void *)d_pt_perm2})
-            if (p) (void)cached_free(p);
-        for (void *p : {(void *)d_pt_ladder, (void *)d_pt_local, (void *)d_pt_all, (void *)d_pt_ladder_thr, (void *)d_pt_perm,
-                        (void *)d_pt_counters})
-            if (p) (void)cached_free(p);
-        for (auto st : lanes) pooled_stream_destroy(st);
-        for (auto ev : lane_events) pooled_event_destroy(ev, true);
-        pooled_event_destroy(fork_event, true);
-        pooled_event_destroy(ev0, false);
-        pooled_event_destroy(ev1, false);
-        pooled_stream_destroy(stream);
-    }
-};
-
-template <typename T>
-static int dev_alloc(T **out, size_t count)
-{
-    *out = nullptr;
-    HIP_TRY(cached_malloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T)));
-    return ISINGMC_OK;
-}
-
-// device scratch of one API call: freed on every exit path, after the stream has drained
-struct DeviceScratch {
-    hipStream_t stream;
-    std::vector<void *> ptrs;
-    explicit DeviceScratch(hipStream_t st) : stream(st) {}
-    DeviceScratch(const DeviceScratch &) = delete;
-    ~DeviceScratch()
-    {
-        if (ptrs.empty()) return;
-        (void)hipStreamSynchronize(stream);
-        for (void *p : ptrs) (void)cached_free(p);
-    }
-    template <typename T>
-    int alloc(T **out, size_t count)
-    {
-        TRY(dev_alloc(out, count));
-        ptrs.push_back(*out);
-        return ISINGMC_OK;
-    }
-};
-
-template <typename T>
-static int graph_upload(isingmc_graph *g, const T **dst, const std::vector<T> &src)
-{
-    T *d = nullptr;
-    TRY(dev_alloc(&d, src.size()));
-    g->dev_allocs.push_back(d);
-    if (!src.empty()) HIP_TRY(hipMemcpy(d, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-    *dst = d;
-    return ISINGMC_OK;
-}
-
-static int use_device(int device)
-{
-    int count = 0;
-    hipError_t err = hipGetDeviceCount(&count);
-    if (err != hipSuccess || count <= 0)
-        return fail(ISINGMC_ERR_NO_DEVICE,
-                    std::string("no HIP device available (libisingmc has no CPU fallback): ") +
-                        hipGetErrorString(err));
-    if (device < 0 || device >= count)
-        return fail(ISINGMC_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range (" +
-                                               std::to_string(count) + " devices)");
-    HIP_TRY(hipSetDevice(device));
-    // the "last error" is per thread and shared with every other HIP user in the process (e.g. torch):
-    // clear what others left behind so that the hipGetLastError() checks after our launches see only ours
-    (void)hipGetLastError();
-    return ISINGMC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// small host helpers
-// ------------------------------------------------------------------------------------------------
-// acceptance probability as a THR_BITS-bit fixed-point threshold: accept iff u < T, u uniform on
-// [0, 2^THR_BITS); T = 2^THR_BITS accepts always (dE <= 0, or beta < 0)
-static uint64_t threshold_fixed(double beta, double dE)
-{
-    const uint64_t ONE = uint64_t(1) << THR_BITS;
-    if (dE <= 0.0) return ONE;
-    const double p = std::exp(-beta * dE);
-    if (!(p < 1.0)) return ONE;
-    return uint64_t(std::floor(std::ldexp(p, THR_BITS)));
-}
-
-static LatThr lattice_thresholds(double beta, double jabs)
-{
-    return LatThr{threshold_fixed(beta, 4.0 * jabs), threshold_fixed(beta, 8.0 * jabs)};
-}
-
-// thresholds of the multi-class kernels (classes: mc_types.hpp); same fixed-point rule, same exp as the two-class ones
-static LatThrMC lattice_thresholds_mc(const isingmc_graph *g, double beta)
-{
-    LatThrMC t{};
-    const int nc = g->mc_mode == MC_FIELD_OPEN ? 9 : g->mc_mode == MC_FIELD ? 6 : g->mc_mode == MC_ANISO ? 5 : 4;
-    for (int c = 0; c < nc; c++) {
-        double dE;
-        if (g->mc_mode == MC_FIELD_OPEN) { // classes by m = sat - unsat and sigma = spin x sign of the site's field: |h| here
-            const int m = c < 8 ? 1 + c / 2 : 0;
-            const double sval = (c == 8 || (c & 1)) ? 1.0 : -1.0;
-            dE = 2.0 * g->jabs * double(m) + 2.0 * std::fabs(g->field) * sval;
-        } else if (g->mc_mode == MC_ANISO) {
-            static const int mx[5] = {2, 2, 0, 2, -2}, my[5] = {2, 0, 2, -2, 2}; // (sat - unsat) per direction of the classes
-            dE = 2.0 * g->jabs * double(mx[c]) + 2.0 * g->jabs_y * double(my[c]); // the oracle's expression, term by term
-        } else if (g->mc_mode == MC_FIELD) {
-            const int k = 2 + c / 2;
-            const double sval = (c & 1) ? 1.0 : -1.0;
-            dE = 2.0 * g->jabs * double(2 * k - 4) + 2.0 * g->field * sval; // the oracle's expression: 2|J|(sat - unsat) + 2 h s
-        } else {
-            dE = 2.0 * g->jabs * double(c + 1);
-        }
-        const uint64_t T = threshold_fixed(beta, dE);
-        if (!(T >> THR_BITS)) t.costly |= 1u << c;
-        t.hi[c] = uint32_t(T >> 32) & ((1u << N_PLANES) - 1);
-        t.lo[c] = uint32_t(T);
-    }
-    return t;
-}
-
-// lattice energy from the integer counters: E = |J| (bonds - 2 satisfied) - h (2 up - N)   (exact in f64 for h = 0)
-static double lattice_energy(const isingmc_graph *g, unsigned long long sat, unsigned long long up)
-{
-    if (g->mc_mode == MC_ANISO) { // sat = satisfied horizontal | satisfied vertical << 32; N bonds per direction
-        const int64_t n = int64_t(g->nvars), sx = int64_t(sat & 0xFFFFFFFFull), sy = int64_t(sat >> 32);
-        return g->jabs * double(n - 2 * sx) + g->jabs_y * double(n - 2 * sy);
-    }
-    if (g->d_fneg) { // sat = satisfied bonds | spins along their site's field << 32; field = |h|
-        const int64_t k = int64_t(sat & 0xFFFFFFFFull), along = int64_t(sat >> 32);
-        return g->jabs * double(int64_t(g->n_edges) - 2 * k) - g->field * double(2 * along - int64_t(g->nvars));
-    }
-    const double bonds = g->jabs * double(int64_t(g->n_edges) - 2 * int64_t(sat));
-    if (g->mc_mode != MC_FIELD && g->mc_mode != MC_FIELD_OPEN) return bonds;
-    return bonds - g->field * double(2 * int64_t(up) - int64_t(g->nvars));
-}
-
-template <typename F>
-static void parallel_for(size_t n, F &&body, size_t bytes_per_item = size_t(1) << 20)
-{
-    // small jobs run on the calling thread: starting and joining threads costs ~100 us, more than expanding a few KB
-    const size_t nthreads = n * bytes_per_item < (size_t(1) << 18)
-                                ? 1 : std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
-    if (nthreads <= 1) {
-        for (size_t i = 0; i < n; i++) body(i);
-        return;
-    }
-    std::vector<std::thread> pool;
-    for (size_t tid = 0; tid < nthreads; tid++)
-        pool.emplace_back([&, tid] {
-            for (size_t i = tid; i < n; i += nthreads) body(i);
-        });
-    for (auto &th : pool) th.join();
-}
-
-// bytes (site order) -> packed words of one replica
-static void pack_state(const isingmc_graph *g, const uint8_t *spins, uint32_t *words)
-{
-    std::fill(words, words + g->state_words, 0u);
-    if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        const LatGeom &L = g->geom;
-        for (uint32_t y = 0; y < L.H; y++)
-            for (uint32_t x = 0; x < L.W; x++)
-                if (spins[size_t(y) * L.W + x]) {
-                    const uint32_t c = (x + y) & 1, i = x >> 1;
-                    words[size_t(c) * L.wpp + size_t(y) * L.wpr + (i >> 5)] |= 1u << (i & 31);
-                }
-    } else {
-        for (uint64_t i = 0; i < g->nvars; i++)
-            if (spins[i]) words[g->pos[i] >> 5] |= 1u << (g->pos[i] & 31);
-    }
-}
-
-// packed words of one replica -> bytes (site order)
-static void unpack_state(const isingmc_graph *g, const uint32_t *words, uint8_t *spins)
-{
-    if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        unpack_lattice(g->geom.W, g->geom.H, words, spins);
-    } else {
-        for (uint64_t i = 0; i < g->nvars; i++) spins[i] = (words[g->pos[i] >> 5] >> (g->pos[i] & 31)) & 1u;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// C ABI: misc + host-only helpers
-// ------------------------------------------------------------------------------------------------
-extern "C" const char *isingmc_last_error(void) { return g_last_error.c_str(); }
-
-extern "C" int isingmc_abi_version(void) { return ISINGMC_ABI_VERSION; }
-
-extern "C" size_t isingmc_release_cached_resources(void)
-{
-    size_t bytes = 0;
-    std::vector<void *> dev_blocks, host_blocks;
-    std::vector<hipStream_t> streams;
-    std::vector<hipEvent_t> events;
-    {
-        DevCache &c = dev_cache();
-        std::lock_guard<std::mutex> lock(c.mu);
-        for (auto &kv : c.idle) dev_blocks.push_back(kv.second);
-        bytes += c.idle_bytes;
-        c.idle.clear();
-        c.idle_bytes = 0;
-    }
-    {
-        HostCache &c = host_cache();
-        std::lock_guard<std::mutex> lock(c.mu);
-        for (auto &kv : c.idle) host_blocks.push_back(kv.second);
-        bytes += c.idle_bytes;
-        c.idle.clear();
-        c.idle_bytes = 0;
-    }
-    {
-        StreamPool &p = stream_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        for (auto &kv : p.idle) streams.push_back(kv.second);
-        p.idle.clear();
-    }
-    {
-        EventPool &p = event_pool();
-        std::lock_guard<std::mutex> lock(p.mu);
-        for (auto &kv : p.idle) events.push_back(kv.second);
-        p.idle.clear();
-    }
-    for (void *b : dev_blocks) (void)hipFree(b);
-    for (void *b : host_blocks) (void)hipHostFree(b);
-    for (hipStream_t st : streams) (void)hipStreamDestroy(st);
-    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
-    (void)hipGetLastError();
-    return bytes;
-}
-
-extern "C" int isingmc_device_count(int *count)
-{
-    if (!count) return fail(ISINGMC_ERR_INVALID, "count is NULL");
-    *count = 0;
-    hipError_t err = hipGetDeviceCount(count);
-    if (err != hipSuccess) {
-        *count = 0;
-        return fail(ISINGMC_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(err));
-    }
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_make_seeds(int has_seed, uint64_t seed_gen, size_t n, uint64_t *seeds_out)
-{
-    if (n && !seeds_out) return fail(ISINGMC_ERR_INVALID, "seeds_out is NULL");
-    const auto seeds = make_seeds(has_seed != 0, seed_gen, n);
-    std::copy(seeds.begin(), seeds.end(), seeds_out);
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_expand_schedule(const uint64_t *stop_t, const double *stop_beta, size_t n_stops,
-                                            size_t timesteps, int compat_constant_beta, double *betas_out)
-{
-    if ((n_stops && (!stop_t || !stop_beta)) || (timesteps && !betas_out))
-        return fail(ISINGMC_ERR_INVALID, "NULL schedule argument");
-    const std::string msg = expand_schedule(stop_t, stop_beta, n_stops, timesteps, compat_constant_beta != 0, betas_out);
-    return msg.empty() ? ISINGMC_OK : fail(ISINGMC_ERR_INVALID, msg);
-}
-
-static int check_edges(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars)
-{
-    if (n_edges == 0) return fail(ISINGMC_ERR_INVALID, "Must supply some edges for graph"); // lattice.rs:70-72
-    if (!ea || !eb || !ej) return fail(ISINGMC_ERR_INVALID, "NULL edge array");
-    if (nvars == 0 || nvars > 0xFFFFFFF0ull) return fail(ISINGMC_ERR_INVALID, "nvars out of range (1 .. 2^32-16)");
-    for (size_t k = 0; k < n_edges; k++) {
-        if (ea[k] >= nvars || eb[k] >= nvars)
-            return fail(ISINGMC_ERR_INVALID, "Index out of bounds: edge " + std::to_string(k) + " touches variable " +
-                                                 std::to_string(std::max(ea[k], eb[k])) + " out of " + std::to_string(nvars));
-        if (!std::isfinite(ej[k])) return fail(ISINGMC_ERR_INVALID, "edge couplings must be finite");
-    }
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_recognise_lattice2d(const uint64_t *ea, const uint64_t *eb, const double *ej,
-                                                size_t n_edges, size_t nvars, int *is_lattice, int *width,
-                                                int *height, double *jabs, int *uniform_sign)
-{
-    if (!is_lattice) return fail(ISINGMC_ERR_INVALID, "is_lattice is NULL");
-    TRY(check_edges(ea, eb, ej, n_edges, nvars));
-    const Lattice2D L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    // bit 0: a W x H lattice; bits 1, 2: open in x, y; bit 3: |J| differs between the directions
-    *is_lattice = L.ok ? 1 + 2 * int(L.open_x) + 4 * int(L.open_y) + 8 * int(L.jabs != L.jabs_y) : 0;
-    if (width) *width = L.W;
-    if (height) *height = L.H;
-    if (jabs) *jabs = L.jabs;
-    if (uniform_sign) *uniform_sign = L.uniform_sign;
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_colour_graph(const uint64_t *ea, const uint64_t *eb, size_t n_edges, size_t nvars,
-                                         uint32_t *colours_out, uint32_t *n_colours_out)
-{
-    std::vector<double> ones(n_edges, 1.0);
-    TRY(check_edges(ea, eb, ones.data(), n_edges, nvars));
-    const Adjacency A = build_adjacency(ea, eb, ones.data(), n_edges, nvars);
-    const Colouring C = greedy_colouring(A, nvars);
-    if (colours_out) std::copy(C.colour.begin(), C.colour.end(), colours_out);
-    if (n_colours_out) *n_colours_out = C.n_colours;
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_pt_swap_round(uint64_t seed, uint64_t round, size_t n_rungs, const double *betas,
-                                          const double *slot_energy, uint32_t *perm, uint64_t *swaps_out)
-{
-    if (n_rungs && (!betas || !slot_energy || !perm)) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    for (size_t i = 0; i < n_rungs; i++)
-        if (perm[i] >= n_rungs) return fail(ISINGMC_ERR_INVALID, "perm is not a permutation of the rungs");
-    const uint64_t swaps = pt_swap_round(seed, round, n_rungs, betas, slot_energy, perm);
-    if (swaps_out) *swaps_out = swaps;
-    return ISINGMC_OK;
-}
-
-// adjacency order -> input-edge order: edge e is the next unfilled entry of both its ends' rows
-template <typename F>
-static void for_each_input_edge(const Adjacency &A, const uint64_t *ea, const uint64_t *eb, size_t n_edges, F &&f)
-{
-    std::vector<uint64_t> fill(A.ptr.begin(), A.ptr.end());
-    for (size_t e = 0; e < n_edges; e++) {
-        if (ea[e] == eb[e]) { f(e, false, 0, 0); continue; }
-        f(e, true, fill[ea[e]], fill[eb[e]]);
-        fill[ea[e]]++;
-        fill[eb[e]]++;
-    }
-}
-
-extern "C" int isingmc_host_rj_energy_levels(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars,
-                                             const double *biases, int32_t *jhi_out, int32_t *jlo_out, int32_t *hhi_out,
-                                             int32_t *hlo_out, int *k_energy_out)
-{
-    TRY(check_edges(ea, eb, ej, n_edges, nvars));
-    if (biases)
-        for (size_t i = 0; i < nvars; i++)
-            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
-    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
-    const RjQuant Q = rj_quantise(A, nvars, biases);
-    if (k_energy_out) *k_energy_out = Q.k_energy;
-    if (hhi_out) std::copy(Q.hhi.begin(), Q.hhi.end(), hhi_out);
-    if (hlo_out) std::copy(Q.hlo.begin(), Q.hlo.end(), hlo_out);
-    for_each_input_edge(A, ea, eb, n_edges, [&](size_t e, bool bond, uint64_t ia, uint64_t) {
-        if (jhi_out) jhi_out[e] = bond ? Q.jhi[ia] : 0;
-        if (jlo_out) jlo_out[e] = bond ? Q.jlo[ia] : 0;
-    });
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_rj_quantise(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges, size_t nvars,
-                                        const double *biases, int32_t *jq_out, int32_t *hq_out, uint8_t *dshift_out, int *k_out,
-                                        int *eligible_out)
-{
-    TRY(check_edges(ea, eb, ej, n_edges, nvars));
-    if (biases)
-        for (size_t i = 0; i < nvars; i++)
-            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
-    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
-    const RjQuant Q = rj_quantise(A, nvars, biases);
-    if (k_out) *k_out = Q.k;
-    if (eligible_out) *eligible_out = Q.eligible;
-    if (hq_out) std::copy(Q.hq.begin(), Q.hq.end(), hq_out);
-    if (dshift_out) std::copy(Q.dshift.begin(), Q.dshift.end(), dshift_out);
-    if (jq_out)
-        for_each_input_edge(A, ea, eb, n_edges, [&](size_t e, bool bond, uint64_t ia, uint64_t ib) {
-            jq_out[2 * e] = bond ? Q.jq[ia] : 0;
-            jq_out[2 * e + 1] = bond ? Q.jq[ib] : 0;
-        });
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_rj_beta(double beta, int k, uint32_t *shift_out, uint32_t *mant_out)
-{
-    if (!shift_out || !mant_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    if (!std::isfinite(beta)) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
-    rj_beta(beta, k, shift_out, mant_out);
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_host_rj_log_table(uint32_t *table_out)
-{
-    if (!table_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    rj_log_table(table_out);
-    return ISINGMC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// graph
-// ------------------------------------------------------------------------------------------------
-// the uniform field h (0 without); fields of one size and both signs (h_i = +-h): |h| and *signs = true;
-// NaN when the biases differ from site to site in any other way
-static double uniform_bias(const double *biases, size_t nvars, bool *signs)
-{
-    *signs = false;
-    if (!biases) return 0.0;
-    bool equal = true, same_size = true;
-    for (size_t i = 1; i < nvars; i++) {
-        equal &= biases[i] == biases[0];
-        same_size &= std::fabs(biases[i]) == std::fabs(biases[0]);
-    }
-    if (equal) return biases[0];
-    if (!same_size) return std::numeric_limits<double>::quiet_NaN();
-    *signs = true;
-    return std::fabs(biases[0]);
-}
-
-// Periodic and field-free: the two-class kernels of lattice_kernels.hpp.  A field |h| <= 2|J| (uniform, or +-h from
-// site to site) on a periodic lattice, open boundaries without a field or with a field |h| <= |J|, anisotropic couplings
-// (periodic, no field): the multi-class kernels (whole quads per row needed).  Anything else (other site-dependent
-// biases, larger fields, anisotropy with a field or open boundaries): the general path.
-static bool lattice_fast_path_ok(const Lattice2D &L, double h, bool field_signs)
-{
-    if (!L.ok || L.W % 64 != 0) return false;
-    if (std::isnan(h)) return false;
-    const bool open = L.open_x || L.open_y, aniso = L.jabs != L.jabs_y;
-    if (aniso && (open || h != 0.0)) return false; // anisotropic couplings: periodic and field-free only
-    if (field_signs && uint64_t(L.W) * uint64_t(L.H) >= (uint64_t(1) << 31)) return false; // two 32-bit counters in one word
-    if (h != 0.0 && !(std::fabs(h) <= 2.0 * L.jabs)) return false;
-    // a boundary site with one more unsatisfied than satisfied bond (m = -1) must still flip outright: |h| <= |J| there
-    if (open && h != 0.0 && !(std::fabs(h) <= L.jabs)) return false;
-    if ((open || h != 0.0 || aniso) && (L.W / 64) % 4 != 0) return false;
-    if (aniso && uint64_t(L.W) * uint64_t(L.H) >= (uint64_t(1) << 32)) return false; // two 32-bit bond counters in one word
-    const uint64_t wpp = uint64_t(L.H) * uint64_t(L.W / 64);
-    // the kernels address a replica through ONE buffer descriptor (int num_records) and 32-bit byte offsets:
-    // both planes must fit below 2^31 bytes; larger lattices take the general path
-    return wpp % 4 == 0 && 2 * wpp * sizeof(uint32_t) < (uint64_t(1) << 31);
-}
-
-static int build_lattice(isingmc_graph *g, const Lattice2D &L, double h, const double *biases, bool field_signs)
-{
-    g->kind = ISINGMC_KIND_LATTICE2D;
-    const bool open = L.open_x || L.open_y;
-    g->mc_mode = h != 0.0 ? (open ? MC_FIELD_OPEN : MC_FIELD) : open ? MC_OPEN : L.jabs != L.jabs_y ? MC_ANISO : MC_NONE;
-    g->jabs_y = L.jabs_y;
-    g->field = h; // signed for a uniform field, |h| with sign planes
-    g->open = McOpen{uint32_t(L.open_x), uint32_t(L.open_y), (!field_signs && h < 0.0) ? 0xFFFFFFFFu : 0u};
-    LatGeom &G = g->geom;
-    G.W = L.W;
-    G.H = L.H;
-    G.wpr = L.W / 64;
-    G.wpp = G.H * G.wpr;
-    G.nquads = G.wpp / 4;
-    g->vec = G.wpr % 4 == 0;
-    G.cols_log2 = -1;
-    if (g->vec) { // division-free, parity-uniform thread mapping (thread_to_quad)
-        const uint32_t cols = G.wpr / 4;
-        if ((cols & (cols - 1)) == 0) {
-            int cl = 0;
-            while ((1u << cl) < cols) cl++;
-            const uint32_t rows_per_pair = cl >= 6 ? 1 : 2 * (64u >> cl);
-            if (G.H % rows_per_pair == 0 && G.nquads % 64 == 0) G.cols_log2 = cl;
-        }
-    }
-    g->jabs = L.jabs;
-    g->uniform_sign = L.uniform_sign;
-    g->jneg_uniform = L.jpos_uniform ? 0u : 0xFFFFFFFFu;
-    g->state_words = 2 * uint64_t(G.wpp);
-    g->n_colours = 2;
-    if (!L.uniform_sign) { // per-bond sign planes in each colour's compact layout
-        std::vector<uint32_t> jneg(size_t(8) * G.wpp, 0u);
-        const uint32_t W = G.W, H = G.H;
-        for (uint32_t c = 0; c < 2; c++)
-            for (uint32_t y = 0; y < H; y++) {
-                const uint32_t yu = (y + H - 1) % H, o = (y + c) & 1;
-                for (uint32_t i = 0; i < W / 2; i++) {
-                    const uint32_t x = 2 * i + o, xl = (x + W - 1) % W;
-                    const bool up = L.jdown[size_t(yu) * W + x], dn = L.jdown[size_t(y) * W + x];
-                    const bool left = L.jright[size_t(y) * W + xl], right = L.jright[size_t(y) * W + x];
-                    const bool ce = o ? left : right, si = o ? right : left;
-                    const size_t w = size_t(y) * G.wpr + (i >> 5);
-                    const uint32_t bit = 1u << (i & 31);
-                    uint32_t *base = jneg.data() + size_t(c) * 4 * G.wpp;
-                    if (!up) base[w] |= bit;
-                    if (!dn) base[G.wpp + w] |= bit;
-                    if (!ce) base[2 * size_t(G.wpp) + w] |= bit;
-                    if (!si) base[3 * size_t(G.wpp) + w] |= bit;
-                }
-            }
-        const uint32_t *d = nullptr;
-        TRY(graph_upload(g, &d, jneg));
-        g->d_jneg = const_cast<uint32_t *>(d);
-    }
-    if (field_signs) { // bit set where h_i < 0, each colour's compact layout
-        std::vector<uint32_t> fneg(size_t(2) * G.wpp, 0u);
-        for (uint32_t c = 0; c < 2; c++)
-            for (uint32_t y = 0; y < G.H; y++) {
-                const uint32_t o = (y + c) & 1;
-                for (uint32_t i = 0; i < G.W / 2; i++)
-                    if (biases[size_t(y) * G.W + 2 * i + o] < 0.0) fneg[size_t(c) * G.wpp + size_t(y) * G.wpr + (i >> 5)] |= 1u << (i & 31);
-            }
-        const uint32_t *d = nullptr;
-        TRY(graph_upload(g, &d, fneg));
-        g->d_fneg = const_cast<uint32_t *>(d);
-    }
-    return ISINGMC_OK;
-}
-
-static bool env_flag(const char *name);
-static int env_int(const char *name, int dflt);
-
-static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *eb, const double *ej,
-                         size_t n_edges, size_t nvars, const double *biases)
-{
-    g->kind = ISINGMC_KIND_GENERAL;
-    const Adjacency A = build_adjacency(ea, eb, ej, n_edges, nvars);
-    if (A.nbr.size() >= 0xFFFFFFFFull) return fail(ISINGMC_ERR_INVALID, "too many edges for the general path (2^32 directed)");
-    const Colouring C = greedy_colouring(A, nvars);
-    if (C.n_pos >= 0xFFFFFFC0ull) return fail(ISINGMC_ERR_INVALID, "too many sites for the general path");
-    g->self_energy = A.self_energy;
-    g->n_colours = C.n_colours;
-    g->class_base = C.class_base;
-    g->pos = C.pos;
-    g->state_words = C.n_pos / 32;
-
-    const uint32_t n_pos = uint32_t(C.n_pos);
-    std::vector<uint32_t> site(n_pos, PAD_SITE), rowptr(size_t(n_pos) + 1, 0);
-    for (size_t i = 0; i < nvars; i++) site[C.pos[i]] = uint32_t(i);
-    for (uint32_t p = 0; p < n_pos; p++)
-        rowptr[p + 1] = rowptr[p] + (site[p] == PAD_SITE ? 0u : uint32_t(A.ptr[site[p] + 1] - A.ptr[site[p]]));
-    std::vector<uint32_t> nbr(A.nbr.size());
-    std::vector<double> w(A.w.size());
-    bool lossless = true;
-    for (uint32_t p = 0; p < n_pos; p++) {
-        if (site[p] == PAD_SITE) continue;
-        uint32_t o = rowptr[p];
-        for (uint64_t e = A.ptr[site[p]]; e < A.ptr[site[p] + 1]; e++, o++) {
-            nbr[o] = uint32_t(C.pos[A.nbr[e]]);
-            w[o] = A.w[e];
-            lossless &= double(float(A.w[e])) == A.w[e];
-        }
-    }
-    GenGraphDev &D = g->gdev;
-    D.n_pos = n_pos;
-    D.n_words = n_pos / 32;
-    g->gen_edges2 = uint32_t(nbr.size());
-    TRY(graph_upload(g, &D.rowptr, rowptr));
-    TRY(graph_upload(g, &D.nbr, nbr));
-    TRY(graph_upload(g, &D.site, site));
-    {
-        std::vector<uint32_t> cb(C.class_base.begin(), C.class_base.end());
-        TRY(graph_upload(g, &D.class_base, cb));
-        D.n_colours = C.n_colours;
-    }
-    g->w_is_float = lossless;
-    if (lossless) { // stream 4-byte couplings when that loses nothing (e.g. J = +-1)
-        std::vector<float> wf(w.begin(), w.end());
-        const float *d = nullptr;
-        TRY(graph_upload(g, &d, wf));
-        D.w = d;
-    } else {
-        const double *d = nullptr;
-        TRY(graph_upload(g, &d, w));
-        D.w = d;
-    }
-    // replica-packed eligibility: one |J| for every bond, no fields, degree <= PK_MAX_DEG
-    {
-        uint64_t maxdeg = 0;
-        for (size_t i = 0; i < nvars; i++) maxdeg = std::max(maxdeg, A.ptr[i + 1] - A.ptr[i]);
-        bool uniform = !w.empty() && !g->has_bias && maxdeg <= PK_MAX_DEG && n_pos < 0x80000000u;
-        const double jabs = w.empty() ? 0.0 : std::fabs(w[0]);
-        for (double x : w) uniform &= std::fabs(x) == jabs;
-        uniform &= jabs > 0.0;
-        if (uniform) {
-            std::vector<uint32_t> ell(size_t(PK_MAX_DEG) * n_pos, PK_NO_NBR); // slot-major: coalesced per slot
-            for (uint32_t p = 0; p < n_pos; p++)
-                for (uint32_t e = rowptr[p]; e < rowptr[p + 1]; e++)
-                    ell[size_t(e - rowptr[p]) * n_pos + p] = nbr[e] | (w[e] > 0.0 ? 0x80000000u : 0u);
-            // block headers: a slot whose 64 entries of a block are one translation (or all unused) needs no table read
-            const size_t n_blocks = n_pos / 64;
-            std::vector<uint2> hdr(n_blocks * PK_MAX_DEG);
-            parallel_for(n_blocks, [&](size_t B) {
-                for (uint32_t i = 0; i < uint32_t(PK_MAX_DEG); i++) {
-                    const uint32_t *e = ell.data() + size_t(i) * n_pos + 64 * B;
-                    const uint32_t p0 = uint32_t(64 * B);
-                    bool unused = true, uniform = e[0] != PK_NO_NBR;
-                    const uint32_t sign = e[0] & 0x80000000u, delta = (e[0] & 0x7FFFFFFFu) - p0;
-                    for (uint32_t l = 0; l < 64; l++) {
-                        unused &= e[l] == PK_NO_NBR;
-                        uniform &= e[l] != PK_NO_NBR && (e[l] & 0x80000000u) == sign && (e[l] & 0x7FFFFFFFu) - (p0 + l) == delta;
-                    }
-                    hdr[B * PK_MAX_DEG + i] = unused ? make_uint2(PK_HDR_UNUSED, 0) : uniform ? make_uint2(PK_HDR_UNIFORM | sign, delta)
-                                                                                           : make_uint2(PK_HDR_MIXED, 0);
-                }
-            });
-            PkGraphDev &P = g->pk;
-            TRY(graph_upload(g, &P.ell_hdr, hdr));
-            TRY(graph_upload(g, &P.nbr_ell, ell));
-            P.site = D.site;
-            P.class_base = D.class_base;
-            P.n_colours = D.n_colours;
-            P.n_pos = n_pos;
-            g->packed_ok = true;
-            g->jabs = jabs;
-            g->n_directed = nbr.size();
-            // one degree, one sign?  (isolated sites have degree 0: they rule the uniform kernel out too)
-            uint64_t mindeg = maxdeg;
-            for (size_t i = 0; i < nvars; i++) mindeg = std::min(mindeg, A.ptr[i + 1] - A.ptr[i]);
-            bool one_sign = true;
-            for (double x : w) one_sign &= (x > 0.0) == (w[0] > 0.0);
-            if (mindeg == maxdeg && maxdeg >= 3) {
-                g->pk_uni_deg = int(maxdeg);
-                g->pk_uni_pmj = !one_sign;
-                g->pk_uni.negmask = w[0] > 0.0 ? 0u : 0xFFFFFFFFu;
-                // this kernel's block headers: translations whatever the signs, the signs as one 64-bit mask per block and slot
-                std::vector<uint2> shift(n_blocks * PK_MAX_DEG, make_uint2(PK_HDR_MIXED, 0)), sign(n_blocks * PK_MAX_DEG, make_uint2(0, 0));
-                parallel_for(n_blocks, [&](size_t B) {
-                    for (uint32_t i = 0; i < uint32_t(maxdeg); i++) {
-                        const uint32_t *e = ell.data() + size_t(i) * n_pos + 64 * B;
-                        const uint32_t p0 = uint32_t(64 * B);
-                        const auto off = [&](uint32_t l) { return (e[l] & 0x7FFFFFFFu) - (p0 + l); };
-                        // the translation of the block: what two of its first three lanes agree on
-                        const uint32_t delta = off(1) == off(2) ? off(1) : off(0);
-                        uint32_t odd_lanes = 0, odd_lane = 0;
-                        uint64_t mask = 0;
-                        for (uint32_t l = 0; l < 64; l++) {
-                            if (e[l] == PK_NO_NBR || off(l) != delta) { odd_lanes++; odd_lane = l; }
-                            mask |= uint64_t(e[l] != PK_NO_NBR && (e[l] >> 31)) << l;
-                        }
-                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, delta);
-                        else if (odd_lanes == 1 && e[odd_lane] != PK_NO_NBR) { // a translation but for one lane (a row's wrap-around)
-                            const int32_t ex = int32_t(off(odd_lane) - delta);
-                            if (ex >= -(1 << 23) && ex < (1 << 23))
-                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), delta);
-                        }
-                        sign[B * PK_MAX_DEG + i] = make_uint2(uint32_t(mask), uint32_t(mask >> 32));
-                    }
-                });
-                for (const uint2 &hd : shift) g->pk_uni_but_one += (hd.x & 3u) == PK_HDR_UNIFORM_BUT_ONE && hd.x != PK_HDR_UNIFORM;
-                TRY(graph_upload(g, &g->pk_uni.shift, shift));
-                TRY(graph_upload(g, &g->pk_uni.sign, sign));
-                g->pk_class_full.resize(C.n_colours);
-                for (uint32_t c = 0; c < C.n_colours; c++) { // real sites come first in a class, the padding after them
-                    uint32_t real = 0;
-                    while (uint32_t(C.class_base[c]) + real < uint32_t(C.class_base[c + 1]) && site[uint32_t(C.class_base[c]) + real] != PAD_SITE) real++;
-                    g->pk_class_full[c] = uint32_t(C.class_base[c]) + real / 256 * 256;
-                }
-                g->pk_class_table.assign(C.n_colours, 0);
-                for (uint32_t c = 0; c < C.n_colours; c++)
-                    for (size_t B = C.class_base[c] / 64; B < g->pk_class_full[c] / 64 && !g->pk_class_table[c]; B++)
-                        for (uint32_t i = 0; i < uint32_t(maxdeg); i++) g->pk_class_table[c] |= (shift[B * PK_MAX_DEG + i].x & 3u) == PK_HDR_MIXED;
-            }
-        }
-    }
-    g->class_real_end.resize(C.n_colours);
-    for (uint32_t c = 0; c < C.n_colours; c++) { // real sites come first in a class
-        uint32_t real = 0;
-        while (uint32_t(C.class_base[c]) + real < uint32_t(C.class_base[c + 1]) && site[uint32_t(C.class_base[c]) + real] != PAD_SITE) real++;
-        g->class_real_end[c] = uint32_t(C.class_base[c]) + real;
-    }
-    // real-coupling packed path: whatever the bit-sliced packed path cannot take (couplings of several sizes, site
-    // biases), degree <= 15, quantisation faithful (rj_quantise)
-    // (ISINGMC_FORCE_REAL=1 at graph creation builds it for graphs the bit-sliced path takes, too: the same Hamiltonian through
-    // the other acceptance rule, for cross-checks such as tools/highstat.py)
-    if ((!g->packed_ok || env_flag("ISINGMC_FORCE_REAL")) && n_pos < 0x80000000u) {
-        const RjQuant Q = rj_quantise(A, nvars, biases);
-        if (Q.eligible) {
-            const uint32_t slots = Q.max_degree <= 4 ? 4u : Q.max_degree <= 7 ? 7u : Q.max_degree <= 11 ? 11u : Q.max_degree <= 15 ? 15u
-                                   : Q.max_degree <= 23 ? 23u : 31u;
-            std::vector<uint32_t> enbr(size_t(slots) * n_pos);
-            std::vector<int32_t> ejq(size_t(slots) * n_pos, 0), ehq(n_pos, 0);
-            std::vector<int32_t> ejhi(size_t(slots) * n_pos, 0), ejlo(size_t(slots) * n_pos, 0), ehhi(n_pos, 0), ehlo(n_pos, 0);
-            std::vector<uint8_t> edsh(n_pos, 0);
-            for (uint32_t i = 0; i < slots; i++)
-                for (uint32_t p = 0; p < n_pos; p++) enbr[size_t(i) * n_pos + p] = p; // unused slots point at the own position
-            for (uint32_t p = 0; p < n_pos; p++) {
-                if (site[p] == PAD_SITE) continue;
-                ehq[p] = Q.hq[site[p]];
-                ehhi[p] = Q.hhi[site[p]];
-                ehlo[p] = Q.hlo[site[p]];
-                edsh[p] = Q.dshift[site[p]];
-                g->rj_heavy_sites += Q.dshift[site[p]] != 0;
-                uint32_t i = 0;
-                for (uint64_t e = A.ptr[site[p]]; e < A.ptr[site[p] + 1]; e++, i++) {
-                    enbr[size_t(i) * n_pos + p] = uint32_t(C.pos[A.nbr[e]]);
-                    ejq[size_t(i) * n_pos + p] = Q.jq[e];
-                    ejhi[size_t(i) * n_pos + p] = Q.jhi[e];
-                    ejlo[size_t(i) * n_pos + p] = Q.jlo[e];
-                }
-            }
-            uint32_t lt[RJ_LOG_INTERVALS + 1];
-            rj_log_table(lt);
-            std::vector<uint2> logtab(RJ_LOG_INTERVALS);
-            for (int i = 0; i < RJ_LOG_INTERVALS; i++) logtab[i] = make_uint2(lt[i], lt[i + 1] - lt[i]);
-            RjGraphDev &J = g->rj;
-            TRY(graph_upload(g, &J.nbr, enbr));
-            TRY(graph_upload(g, &J.jq, ejq));
-            TRY(graph_upload(g, &J.hq, ehq));
-            TRY(graph_upload(g, &J.logtab, logtab));
-            J.dshift = nullptr;
-            if (Q.heavy) TRY(graph_upload(g, &J.dshift, edsh));
-            J.n_pos = n_pos;
-            J.slots = slots;
-            g->rj_hi = g->rj_lo = J;
-            TRY(graph_upload(g, &g->rj_hi.jq, ejhi));
-            TRY(graph_upload(g, &g->rj_hi.hq, ehhi));
-            TRY(graph_upload(g, &g->rj_lo.jq, ejlo));
-            TRY(graph_upload(g, &g->rj_lo.hq, ehlo));
-            g->rj_k = Q.k;
-            g->rj_k_energy = Q.k_energy;
-            g->rj_ok = true;
-            // the packed containers' common parts (random start, set_state, copy-out) read these
-            g->pk.site = D.site;
-            g->pk.class_base = D.class_base;
-            g->pk.n_colours = D.n_colours;
-            g->pk.n_pos = n_pos;
-        }
-    }
-    D.bias = nullptr;
-    if (g->has_bias) {
-        std::vector<double> bias(n_pos, 0.0);
-        for (size_t i = 0; i < nvars; i++) bias[C.pos[i]] = biases[i];
-        TRY(graph_upload(g, &D.bias, bias));
-    }
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_graph_create(const uint64_t *ea, const uint64_t *eb, const double *ej, size_t n_edges,
-                                    size_t nvars, const double *biases, int device, unsigned flags,
-                                    isingmc_graph **graph_out)
-{
-    if (!graph_out) return fail(ISINGMC_ERR_INVALID, "graph_out is NULL");
-    *graph_out = nullptr;
-    TRY(check_edges(ea, eb, ej, n_edges, nvars));
-    bool has_bias = false;
-    if (biases)
-        for (size_t i = 0; i < nvars; i++) {
-            if (!std::isfinite(biases[i])) return fail(ISINGMC_ERR_INVALID, "biases must be finite");
-            has_bias |= biases[i] != 0.0;
-        }
-    TRY(use_device(device));
-    auto g = std::make_unique<isingmc_graph>();
-    g->device = device;
-    g->nvars = nvars;
-    g->n_edges = n_edges;
-    g->has_bias = has_bias;
-    g->stable_path = (flags & ISINGMC_FLAG_STABLE_PATH) != 0 || env_flag("ISINGMC_STABLE_PATH");
-    Lattice2D L;
-    bool field_signs = false;
-    const double h = has_bias ? uniform_bias(biases, nvars, &field_signs) : 0.0;
-    if (!(flags & ISINGMC_FLAG_FORCE_GENERAL) && !std::isnan(h)) L = recognise_lattice2d(ea, eb, ej, n_edges, nvars);
-    if (lattice_fast_path_ok(L, h, field_signs)) TRY(build_lattice(g.get(), L, h, biases, field_signs));
-    else TRY(build_general(g.get(), ea, eb, ej, n_edges, nvars, biases));
-    *graph_out = g.release();
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_graph_info(const isingmc_graph *g, isingmc_graph_info_t *info)
-{
-    if (!g || !info) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    std::memset(info, 0, sizeof *info);
-    info->kind = g->kind;
-    info->device = g->device;
-    info->nvars = g->nvars;
-    info->n_edges = g->n_edges;
-    if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        info->width = int32_t(g->geom.W);
-        info->height = int32_t(g->geom.H);
-        info->jabs = g->jabs;
-        info->jabs_y = g->mc_mode == MC_ANISO ? g->jabs_y : g->jabs;
-        info->uniform_sign = g->uniform_sign;
-        info->fast_path = g->mc_mode;
-        info->field = g->field;
-        info->open_x = int32_t(g->open.open_x);
-        info->open_y = int32_t(g->open.open_y);
-        info->field_signs = g->d_fneg ? 1 : 0;
-    }
-    info->n_colours = g->n_colours;
-    info->packed_degree = g->packed_ok ? g->pk_uni_deg : 0;
-    info->packed_but_one_headers = g->packed_ok ? int32_t(g->pk_uni_but_one) : 0;
-    info->real_slots = g->rj_ok ? int32_t(g->rj.slots) : 0;
-    info->real_quantum_log2 = g->rj_ok ? g->rj_k : 0;
-    info->real_energy_log2 = g->rj_ok ? g->rj_k_energy : 0;
-    info->real_heavy_sites = g->rj_ok ? int32_t(g->rj_heavy_sites) : 0;
-    info->stable_path = g->stable_path ? 1 : 0;
-    info->state_words = g->state_words;
-    return ISINGMC_OK;
-}
-
-extern "C" void isingmc_graph_destroy(isingmc_graph *g) { delete g; }
+// libisingmc.so: replica containers and every Monte-Carlo launch of the C ABI of include/isingmc.h (gfx950 only).
+// Host orchestration only -- every Monte-Carlo operation runs in the kernels of lattice_kernels.hpp / general_kernels.hpp /
+// packed_kernels.hpp (+ the strip, spread, multi-class, one-degree and real-coupling translation units).  There is no CPU fallback.
+// (internal.hpp: how the host side is cut into translation units.)
+#include "internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // states
@@ -1236,19 +13,17 @@ static dim3 lat_grid(const isingmc_graph *g, uint32_t quads, size_t replicas)
     return dim3((quads + 255) / 256, unsigned(replicas), 1);
 }
 
-constexpr size_t MAX_GRID_Y = 32768;
 
 static int lanes_reserve(isingmc_states *s, size_t n);
 static int lanes_fork(isingmc_states *s, size_t n);
 static int lanes_join(isingmc_states *s);
 
 // replica-packed general path (defined further down)
-static int choose_packed(const isingmc_graph *g, size_t n_replicas);
+static int choose_packed(const isingmc_states *s, size_t n_replicas);
 static int pk_create(isingmc_states *s, const uint64_t *all_seeds, size_t first, size_t n, const uint8_t *initial_state);
 static int pk_set_state(isingmc_states *s, size_t replica, const uint8_t *spins);
 static int pk_set_betas(isingmc_states *s);
 static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_state);
-static bool resident_disabled();
 
 // random start for replicas [first, first+count)
 static int init_random(isingmc_states *s, size_t first, size_t count)
@@ -1364,7 +139,8 @@ extern "C" int isingmc_states_create_range(isingmc_graph *g, size_t n_total, con
     TRY(lanes_reserve(s.get(), 2)); // created up front: the first multi-lane run must not pay for stream creation
     s->n_total = n_total;
     s->first = first;
-    if (const int mode = count ? choose_packed(g, n_total) : 0) {
+    s->opt = Options::from_env();
+    if (const int mode = count ? choose_packed(s.get(), n_total) : 0) {
         s->rj = mode == 2;
         TRY(pk_create(s.get(), all_seeds, first, count, initial_state));
     } else {
@@ -1416,7 +192,17 @@ extern "C" int isingmc_states_set_timestep(isingmc_states *s, uint64_t t)
 
 extern "C" void isingmc_states_destroy(isingmc_states *s) { delete s; }
 
-static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal);
+extern "C" int isingmc_states_set_option(isingmc_states *s, const char *name, long value)
+{
+    if (!s || !name) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    const std::string n(name);
+    for (const char *family : {"force_real", "disable_real", "force_packed", "disable_packed"})
+        if (n.find(family) != std::string::npos && (n.size() == std::strlen(family) || n.size() == std::strlen(family) + 8))
+            return fail(ISINGMC_ERR_INVALID, "the kernel family of a container is fixed when it is created (set ISINGMC_" + std::string(family) +
+                                                 " in the environment before isingmc_states_create)");
+    if (!s->opt.set(n, value)) return fail(ISINGMC_ERR_INVALID, "unknown option '" + n + "'");
+    return ISINGMC_OK;
+}
 
 extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_per_replica)
 {
@@ -1424,7 +210,7 @@ extern "C" int isingmc_states_set_betas(isingmc_states *s, const double *beta_pe
 }
 
 // all_equal: the caller passes one beta R times (run_sampling) -- then a shard that cuts a replica group is fine
-static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal)
+int set_betas(isingmc_states *s, const double *beta_per_replica, bool all_equal)
 {
     if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
     if (!beta_per_replica) {
@@ -1473,17 +259,6 @@ static int set_betas(isingmc_states *s, const double *beta_per_replica, bool all
 // replica-packed general path (packed_kernels.hpp): state = uint32[groups][n_pos], group g = replicas
 // 32g .. 32g+31, keyed by the seed of its first replica
 // ------------------------------------------------------------------------------------------------
-static bool env_flag(const char *name)
-{
-    const char *e = std::getenv(name);
-    return e && e[0] && e[0] != '0';
-}
-
-static int env_int(const char *name, int dflt)
-{
-    const char *e = std::getenv(name);
-    return e && e[0] ? std::atoi(e) : dflt;
-}
 
 // worth it from 16 replicas on and when the graph is too big for the LDS-resident per-replica kernel
 // LDS-resident kernel for small graphs only: one workgroup walks a whole replica, ~13 us + 2.8..5 ns per site
@@ -1517,17 +292,19 @@ static bool packed_worth_it(const isingmc_graph *g, size_t n_replicas, bool real
 }
 
 // 0: one replica per word set (CSR kernels); 1: replica-packed bit-sliced path (S6); 2: replica-packed real-coupling path (S7)
-static int choose_packed(const isingmc_graph *g, size_t n_replicas)
+static int choose_packed(const isingmc_states *s, size_t n_replicas)
 {
-    if (g->rj_ok && !env_flag("ISINGMC_DISABLE_REAL") && (!g->packed_ok || env_flag("ISINGMC_FORCE_REAL"))) {
+    const isingmc_graph *g = s->g;
+    const Options &o = s->opt;
+    if (g->rj_ok && !o.disable_real && (!g->packed_ok || o.force_real)) {
         // (stable_path: the family follows from the graph alone -- experiment k must not change when the call asks for more of them)
-        if (env_flag("ISINGMC_FORCE_REAL") || g->stable_path) return n_replicas > 0 ? 2 : 0;
+        if (o.force_real || g->stable_path) return n_replicas > 0 ? 2 : 0;
         return packed_worth_it(g, n_replicas, true) ? 2 : 0;
     }
-    if (!g->packed_ok || env_flag("ISINGMC_DISABLE_PACKED")) return 0;
+    if (!g->packed_ok || o.disable_packed) return 0;
     // pk_sweep_kernel addresses the ELL table through one buffer descriptor with 32-bit byte offsets
     if (uint64_t(g->pk.n_pos) * PK_MAX_DEG * sizeof(uint32_t) >= (uint64_t(1) << 31)) return 0;
-    if (env_flag("ISINGMC_FORCE_PACKED") || g->stable_path) return n_replicas > 0 ? 1 : 0;
+    if (o.force_packed || g->stable_path) return n_replicas > 0 ? 1 : 0;
     return packed_worth_it(g, n_replicas, false) ? 1 : 0;
 }
 
@@ -1682,7 +459,7 @@ static int pk_set_betas(isingmc_states *s)
 static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t beta_stride, size_t gb, size_t ge, hipStream_t stream)
 {
     const isingmc_graph *g = s->g;
-    static const int target_wgs = std::max(256, env_int("ISINGMC_REAL_TARGET_WGS", 3072));
+    const int target_wgs = s->opt.real_target_wgs;
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = g->class_real_end[c];
         if (e == b) continue;
@@ -1716,7 +493,7 @@ static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t 
 static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride, size_t gb, size_t ge, hipStream_t stream)
 {
     const isingmc_graph *g = s->g;
-    const bool no_uni = env_flag("ISINGMC_DISABLE_PACKED_UNIFORM"); // A/B switch: results are the same either way
+    const bool no_uni = s->opt.disable_packed_uniform != 0; // A/B switch: results are the same either way
     for (uint32_t c = 0; c < g->n_colours; c++) {
         const uint32_t b = uint32_t(g->class_base[c]), e = uint32_t(g->class_base[c + 1]);
         if (e == b) continue;
@@ -1737,10 +514,9 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
     }
 }
 
-static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up = true);
 
 // energy of one replica of a packed container from the counters of its slot
-static double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0, unsigned long long c1)
+double pk_energy(const isingmc_graph *g, bool rj, unsigned long long c0, unsigned long long c1)
 {
     // real-coupling path: c0, c1 = -2 x the hi / lo level sums of the energy (exact, even integers; rj_measure_kernel, run once
     // per level): E = (2^kE hi + 2^(kE - 24) lo) + self loops -- the energy of the ORIGINAL couplings to Fmax 2^-54 per term
@@ -1802,7 +578,7 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
         uint64_t biggest = 0;
         for (uint32_t c = 0; c < g->n_colours; c++) biggest = std::max<uint64_t>(biggest, g->class_base[c + 1] - g->class_base[c]);
         const uint64_t waves_per_launch = s->groups * biggest / (s->rj ? 64 : 256); // a thread decides 1 (real) / 4 (bit-sliced) positions
-        const int forced = env_int("ISINGMC_PK_STREAMS", 0);
+        const int forced = s->opt.pk_streams;
         if (forced > 0) want_lanes = size_t(forced);
         // measured (tools/pk_lanes_ab.py, profiles/r03_pk_lanes_ab.txt): two lanes +7 % (2048^2 x 256) to +43 % (512^2 x 64) from ~2 000 waves per
         // launch on, -3..-13 % below (32^3 x 64: the launches are too short for the fork / join); four lanes: worse than two almost everywhere
@@ -1877,7 +653,7 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
 }
 
 // packed words -> one byte per spin, replica by replica
-static int pk_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes, uint32_t *packed_out)
+int pk_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes, uint32_t *packed_out)
 {
     const isingmc_graph *g = s->g;
     std::vector<uint32_t> words(s->groups * g->pk.n_pos);
@@ -1916,7 +692,7 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
         for (size_t r0 = lo; r0 < hi; r0 += MAX_GRID_Y) {
             const size_t n = std::min(MAX_GRID_Y, hi - r0);
             // diagnostic: ISINGMC_DEBUG_SWEEP_LDS=<bytes> of unused LDS per workgroup lowers the occupancy
-            static const unsigned dbg_lds = [] { const char *e = getenv("ISINGMC_DEBUG_SWEEP_LDS"); return e ? unsigned(atoi(e)) : 0u; }();
+            const unsigned dbg_lds = unsigned(std::max(0, s->opt.debug_sweep_lds));
             const auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, lat_grid(g, g->geom.nquads, n), dim3(256), dbg_lds, stream,
                                    s->d_state + r0 * g->state_words, g->geom, colour, t_arg, s->d_keys + r0, thr,
@@ -1927,7 +703,7 @@ static void launch_lat_sweep(isingmc_states *s, uint32_t colour, const LatThr &t
             // ISINGMC_SWEEP_ITERS=1|2|4|8 forces the choice (measurement only)
             uint32_t iters = 1;
             if (VEC && g->geom.cols_log2 >= 0) {
-                static const int forced = [] { const char *e = getenv("ISINGMC_SWEEP_ITERS"); return e ? atoi(e) : 0; }();
+                const int forced = s->opt.sweep_iters;
                 const uint32_t want = forced ? uint32_t(forced) : 2u;
                 if (want > 1 && g->geom.nquads % (256 * want) == 0 &&
                     (forced || size_t(g->geom.nquads / (256 * want)) * n >= size_t(8) * 256)) // >= 8 workgroups per CU left (c4: +2.6 %)
@@ -2116,22 +892,12 @@ static int measure(isingmc_states *s, double *energies, int64_t *mags)
     return ISINGMC_OK;
 }
 
-// ISINGMC_DISABLE_RESIDENT=1: always use the per-colour launches (A/B runs, parity tests of both paths)
-static bool resident_disabled()
-{
-    const char *e = std::getenv("ISINGMC_DISABLE_RESIDENT");
-    return e && e[0] && e[0] != '0';
-}
+// ISINGMC_DISABLE_RESIDENT=1 (at creation): always use the per-colour launches (A/B runs, parity tests of both paths)
+static bool resident_disabled(const isingmc_states *s) { return s->opt.disable_resident != 0; }
 
 // ------------------------------------------------------------------------------------------------
 // persistent strip kernel (strip_kernels.hpp): when and how
 // ------------------------------------------------------------------------------------------------
-struct StripPlan {
-    bool use = false;
-    int nw = 1; // waves per strip (workgroup)
-    StripArgs a{};
-    size_t replicas_per_pass = 0; // a pass = one launch over a block of replicas for all timesteps of the chunk
-};
 
 // Mid-size lattices only: a per-colour launch of the streaming kernel must be short enough for the ~5 us it loses
 // between dependent launches to matter (<= ISINGMC_STRIP_MAX_WG workgroups in all, default the resident limit), the geometry must cut into strips of 256 quads with at least two strips per replica, and the poll of a
@@ -2150,15 +916,15 @@ static int strip_resident_blocks_per_cu(bool pmj, int nw, bool ladder, size_t ld
     return n;
 }
 
-static StripPlan strip_plan(const isingmc_states *s, size_t timesteps, bool ladder = false)
+StripPlan strip_plan(const isingmc_states *s, size_t timesteps, bool ladder)
 {
     StripPlan P;
     const isingmc_graph *g = s->g;
-    const int mode = env_int("ISINGMC_STRIP", -1);
+    const int mode = s->opt.strip;
     if (mode == 0 || s->strip_disabled || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
     const uint32_t qpr = g->geom.wpr / 4;
     if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, at least two rows per wave
-    P.nw = env_int("ISINGMC_STRIP_NW", 4) == 1 ? 1 : 4; // measured on 1024^2 x 64: 9.6 us per timestep either way; with exchange rounds 11.5 (4) / 12.0 (1)
+    P.nw = s->opt.strip_nw == 1 ? 1 : 4; // measured on 1024^2 x 64: 9.6 us per timestep either way; with exchange rounds 11.5 (4) / 12.0 (1)
     const uint32_t S = 64 * uint32_t(P.nw) / qpr;
     if (g->geom.H % S != 0 || g->geom.H / S < 2) return P;
     int dev_cus = 256;
@@ -2173,7 +939,7 @@ static StripPlan strip_plan(const isingmc_states *s, size_t timesteps, bool ladd
     const size_t n_strips = g->geom.H / S, total = s->R * n_strips;
     if (limit == 0 || n_strips > limit) return P;
     // one pass only by default: with twice the replicas (1024^2 x 128) the per-colour launches are long enough to win (16.7 vs 18.6 us)
-    if (mode != 1 && total > size_t(env_int("ISINGMC_STRIP_MAX_WG", int(limit)))) return P;
+    if (mode != 1 && total > size_t(s->opt.strip_max_wg >= 0 ? s->opt.strip_max_wg : int(limit))) return P;
     const size_t passes = (total + limit - 1) / limit;
     P.replicas_per_pass = (s->R + passes - 1) / passes;
     while (P.replicas_per_pass * n_strips > limit) P.replicas_per_pass--;
@@ -2192,8 +958,8 @@ static std::mutex g_strip_mutex;
 static hipEvent_t g_strip_done[64] = {};
 
 // one pass: replicas [r0, r0 + n) for timesteps [s->t, s->t + nk).  steps_out / final_out: see lat_strip_kernel
-static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t n, size_t nk, const LatThr *d_thr_steps,
-                        uint32_t thr_stride, unsigned long long *steps_out, double *final_energies, const StripLadder *ladder = nullptr)
+int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t n, size_t nk, const LatThr *d_thr_steps,
+                 uint32_t thr_stride, unsigned long long *steps_out, double *final_energies, const StripLadder *ladder)
 {
     const isingmc_graph *g = s->g;
     const size_t granules = s->cap * size_t(P.a.n_strips) * 4 * g->geom.wpr;
@@ -2226,7 +992,7 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
     // test hook (tests/test_gpu_strip.py): the first strip launch of this object runs with the error word already raised,
     // as if a workgroup had timed out -- in-order dispatch makes a real timeout need a co-tenant or a replica of more strips
     // than the chip holds -- so that the host's recovery (restore the planes, repeat on the per-colour launches) is exercised
-    if (!s->strip_test_failed && env_flag("ISINGMC_STRIP_TEST_FAIL_ONCE")) {
+    if (!s->strip_test_failed && s->opt.strip_test_fail_once) {
         const uint32_t one = STRIP_ERR_TIMEOUT;
         HIP_TRY(hipMemcpyAsync(s->d_strip_err, &one, sizeof one, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -2253,8 +1019,7 @@ static int launch_strip(isingmc_states *s, const StripPlan &P, size_t r0, size_t
 // after a synchronisation: did a strip launch give up (its workgroups were not all resident)?  Then everything the strip
 // kernels share between launches is reset and the object takes the per-colour launches from now on.  Callers that kept
 // the planes they started from (run_steps, isingmc_run_sampling) repeat their work; the others report the error.
-constexpr int STRIP_TIMED_OUT = 1000; // internal status, never returned through the C ABI
-static int strip_check(isingmc_states *s)
+int strip_check(isingmc_states *s)
 {
     if (!s->d_strip_err) return ISINGMC_OK;
     uint32_t h = 0;
@@ -2271,7 +1036,7 @@ static int strip_check(isingmc_states *s)
     return STRIP_TIMED_OUT;
 }
 
-static int strip_error(int rc)
+int strip_error(int rc)
 {
     if (rc != STRIP_TIMED_OUT) return rc;
     return fail(ISINGMC_ERR_HIP, "the persistent strip kernel timed out waiting for a neighbour strip (its workgroups were not all "
@@ -2285,7 +1050,7 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
 
 // planes of a states object before a call that may launch the strip kernel (D2D copy on the engine's stream: ~3 us for
 // 1024^2 x 64), so that a timeout costs a repeat of the call instead of the configurations
-static int snapshot_take(isingmc_states *s)
+int snapshot_take(isingmc_states *s)
 {
     const size_t words = s->R * s->g->state_words;
     if (s->snapshot_cap < words) {
@@ -2300,20 +1065,20 @@ static int snapshot_take(isingmc_states *s)
     return ISINGMC_OK;
 }
 
-static int snapshot_restore(isingmc_states *s)
+int snapshot_restore(isingmc_states *s)
 {
     HIP_TRY(hipMemcpyAsync(s->d_state, s->d_snapshot, s->R * s->g->state_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
     return ISINGMC_OK;
 }
 
-static bool may_use_strips(const isingmc_states *s)
+bool may_use_strips(const isingmc_states *s)
 {
     return s && s->R && !s->packed && !s->strip_disabled && s->g->kind == ISINGMC_KIND_LATTICE2D && s->g->mc_mode == MC_NONE &&
-           env_int("ISINGMC_STRIP", -1) != 0;
+           s->opt.strip != 0;
 }
 
-static int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
-                     double *energies_per_step, float *device_ms, bool sync = true, double *final_energies = nullptr)
+int run_steps(isingmc_states *s, size_t timesteps, const double *betas, size_t beta_stride,
+              double *energies_per_step, float *device_ms, bool sync, double *final_energies)
 {
     // a synchronous call keeps the planes it started from when it may launch the strip kernel; if a launch gives up (its
     // workgroups were not all resident: a co-tenant, a CU mask) the call is repeated with the per-colour launches
@@ -2357,15 +1122,15 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
     // lattices with a field or open boundaries: the multi-class kernels, one launch per colour (+ one measurement per step)
     const bool mc = lattice && g->mc_mode != MC_NONE;
     const bool resident = lattice && !mc && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 &&
-                          !resident_disabled();
+                          !resident_disabled(s);
     // per-step counters: 16 B per (step, replica) and counter slot, at most 32 MiB per chunk on each side of the bus
     const StripPlan strip = (lattice && !resident && !mc) ? strip_plan(s, timesteps) : StripPlan{};
     s->meas_fresh = false;
     const size_t step_slots = (energies_per_step && lattice && !resident && !strip.use && !mc) ? MEASURE_SLOTS : 1;
     size_t chunk = energies_per_step ? std::max<size_t>(1, std::min<size_t>(timesteps, (size_t(32) << 20) / (16 * R * step_slots))) : timesteps;
-    const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled();
+    const bool gen_resident = !lattice && gen_resident_fits(g, R) && !resident_disabled(s);
     // the multi-class modes' LDS-resident kernel: same size bound
-    const bool mc_resident = mc && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 && !resident_disabled();
+    const bool mc_resident = mc && g->state_words * sizeof(uint32_t) <= LDS_RESIDENT_MAX_BYTES && g->geom.nquads <= 1024 && !resident_disabled(s);
     if (resident || gen_resident || strip.use || mc_resident) chunk = std::min<size_t>(chunk, 65536);
     DeviceScratch scratch(s->stream);
     double *d_beta_steps = nullptr, *d_gen_energies = nullptr;
@@ -2394,8 +1159,7 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
     size_t want_lanes = 1;
     if (lattice && !resident && !strip.use && !mc_resident && !energies_per_step) { // the multi-class kernels' launches too
         const size_t waves_per_launch = R * ((g->geom.nquads + 255) / 256) * 4;
-        const char *e = std::getenv("ISINGMC_STREAMS");
-        if (e) want_lanes = std::max(1, std::atoi(e));
+        if (s->opt.streams > 0) want_lanes = size_t(s->opt.streams);
         // < 64 waves per SIMD per launch: +17..33 % with 2 lanes (4 go host-bound); short calls lose it to fork/join.
         // Large launches: +2.8 % (one block's drain overlaps the other's ramp); the fork/join is ~45 us per call
         else if (waves_per_launch < 64 * 1024 ? timesteps >= 64 : timesteps >= 8) want_lanes = 2;
@@ -2420,10 +1184,10 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
             // ... while every replica of the call is resident at once: beyond that the one-lane-per-quad kernel's small workgroups fill
             // the chip better (measured, tools/small_lattice_spread_ab.py: 64^2 x 2048 4.1 against 5.9 us, x 4096 10.5 against 9.1;
             // 128^2 x 512 4.4 against 5.4, x 1024 8.7 against 5.3).  ISINGMC_RESIDENT_SPREAD=0 / 2: never / whenever the lattice allows
-            static const int spread_mode = env_int("ISINGMC_RESIDENT_SPREAD", 1);
+            const int spread_mode = s->opt.resident_spread;
             // eight lanes per quad only: with four or two (256 / 512 quads per colour, 1024 threads) the barriers of a 16-wave workgroup
             // cost more than the shorter chain saves (256^2 x 64: 5.7 against 5.1 us; ISINGMC_RESIDENT_LPQ=4 / 2 for A/B runs)
-            static const int lpq_forced = env_int("ISINGMC_RESIDENT_LPQ", 0);
+            const int lpq_forced = s->opt.resident_lpq;
             const int lpq = lpq_forced == 4 || lpq_forced == 2 ? lpq_forced : 8;
             bool spread = spread_mode != 0 && size_t(g->geom.nquads) * size_t(lpq) <= 1024;
             const unsigned spread_threads = unsigned((size_t(g->geom.nquads) * size_t(lpq) + 63) / 64 * 64);
@@ -2479,7 +1243,7 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
             }
             // small lattices, few enough replicas to be resident at once: eight lanes per quad (lat_mc_resident_kernel SPREAD; the
             // kernel takes the spread form when the launch's LDS holds the random words too).  ISINGMC_RESIDENT_SPREAD=0: off
-            static const int mc_spread_mode = env_int("ISINGMC_RESIDENT_SPREAD", 1);
+            const int mc_spread_mode = s->opt.resident_spread;
             int mc_n_cu = 256;
             (void)hipDeviceGetAttribute(&mc_n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
             const size_t spread_threads = (size_t(g->geom.nquads) * 8 + 63) / 64 * 64;
@@ -2508,7 +1272,7 @@ static int run_steps_impl(isingmc_states *s, size_t timesteps, const double *bet
             // the graph in LDS too (gen_resident_kernel STAGE) while every replica of the call can still be resident at once (160 KB
             // of LDS per compute unit): small graphs, where a timestep is a chain of dependent loads.  Everything when that fits,
             // else the topology alone (the links of the chain); ISINGMC_GEN_STAGE=0 / 1 / 2 forces none / all / topology (A/B runs)
-            static const int stage_mode = env_int("ISINGMC_GEN_STAGE", -1);
+            const int stage_mode = s->opt.gen_stage;
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
             const size_t lds_cu = 160 * 1024, lds_max = 150 * 1024; // (a few KB stay free for the kernel's static LDS)
@@ -2669,50 +1433,10 @@ extern "C" int isingmc_get_packed_states(isingmc_states *s, uint32_t *words_out)
     return ISINGMC_OK;
 }
 
-static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies);
-static void madvise_hugepages(void *p, size_t bytes);
-
-extern "C" int isingmc_get_states(isingmc_states *s, uint8_t *states_out, size_t replica_stride_bytes)
-{
-    if (!s || !states_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    if (replica_stride_bytes < s->g->nvars) return fail(ISINGMC_ERR_INVALID, "replica stride smaller than nvars");
-    TRY(use_device(s->g->device));
-    const isingmc_graph *g = s->g;
-    if (s->packed) return s->R ? pk_get_states(s, states_out, replica_stride_bytes, nullptr) : ISINGMC_OK;
-    // packed device words -> pinned host memory in slabs of replicas (<= 64 MiB), two in flight on the copy stream, expanded
-    // to bytes by the host threads while the next slab crosses PCIe (the buffers of the sampling pipeline)
-    if (s->R == 0) return ISINGMC_OK;
-    const size_t slab = std::max<size_t>(1, std::min<size_t>(s->R, (size_t(64) << 20) / (g->state_words * 4)));
-    const size_t n_slabs = (s->R + slab - 1) / slab;
-    TRY(sampling_reserve(s, slab * g->state_words, 0, 0));
-    madvise_hugepages(states_out, s->R * replica_stride_bytes);
-    HIP_TRY(hipEventRecord(s->sample_ready[0], s->stream)); // everything queued on the engine's stream comes first
-    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->sample_ready[0], 0));
-    const auto copy_slab = [&](size_t j) {
-        const size_t r0 = j * slab, n = std::min(slab, s->R - r0);
-        HIP_TRY(hipMemcpyAsync(s->h_samples[j & 1], s->d_state + r0 * g->state_words, n * g->state_words * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, s->copy_stream));
-        HIP_TRY(hipEventRecord(s->sample_copied[j & 1], s->copy_stream));
-        return int(ISINGMC_OK);
-    };
-    TRY(copy_slab(0));
-    for (size_t j = 0; j < n_slabs; j++) {
-        HIP_TRY(hipEventSynchronize(s->sample_copied[j & 1]));
-        if (j + 1 < n_slabs) TRY(copy_slab(j + 1)); // into the other buffer, which slab j-1's expansion has released
-        const size_t r0 = j * slab, n = std::min(slab, s->R - r0);
-        const uint32_t *words = s->h_samples[j & 1];
-        parallel_for(n, [&](size_t i) { unpack_state(g, words + i * g->state_words, states_out + (r0 + i) * replica_stride_bytes); }, g->nvars);
-    }
-    return ISINGMC_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
-// sampling run: thermalise, then S x { freq timesteps; record state + energy }  (lattice.rs:271-287,
-// classicising.rs:144-173).  Everything is enqueued on the stream -- sweeps, a device-to-device copy of
-// the packed configurations into a sample ring, the measurement kernels -- and the host only waits once
-// per chunk of samples (<= 512 MiB of packed states), then expands the bits to bools on its threads.
+// measurements enqueued behind the sweeps (per-step energies, sampling, tempering rounds)
 // ------------------------------------------------------------------------------------------------
-static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up)
+int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, double *e_slot, long long *m_slot, bool want_up)
 {
     const isingmc_graph *g = s->g;
     const size_t R = s->R;
@@ -2781,698 +1505,7 @@ static int measure_enqueue(isingmc_states *s, unsigned long long *counts_slot, d
     return ISINGMC_OK;
 }
 
-// buffers of the sampling pipeline, grown on demand and kept for the next call (pinning host memory is slow)
-template <typename T>
-static int regrow(T **dev, T **host, size_t count)
+void lat_measure_enqueue(isingmc_states *s, unsigned long long *out, size_t out_stride)
 {
-    if (*dev) HIP_TRY(cached_free(*dev));
-    if (*host) HIP_TRY(cached_host_free(*host));
-    *dev = nullptr;
-    *host = nullptr;
-    TRY(dev_alloc(dev, count));
-    HIP_TRY(cached_host_malloc(reinterpret_cast<void **>(host), std::max<size_t>(count, 1) * sizeof(T)));
-    return ISINGMC_OK;
+    LAT_DISPATCH(launch_lat_measure, s, out, out_stride);
 }
-
-static int sampling_reserve(isingmc_states *s, size_t words, size_t counts, size_t energies)
-{
-    if (!s->copy_stream) HIP_TRY(pooled_stream_create(&s->copy_stream));
-    HIP_TRY(stream_quiesce(s->stream)); // buffers regrown below go through the block caches
-    HIP_TRY(stream_quiesce(s->copy_stream));
-    for (int b = 0; b < 2; b++) {
-        if (!s->sample_ready[b]) HIP_TRY(pooled_event_create(&s->sample_ready[b], true));
-        if (!s->sample_copied[b]) HIP_TRY(pooled_event_create(&s->sample_copied[b], true));
-    }
-    HIP_TRY(hipStreamSynchronize(s->copy_stream));
-    if (words > s->sample_cap_words) {
-        s->sample_cap_words = 0;
-        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_samples[b], &s->h_samples[b], words));
-        s->sample_cap_words = words;
-    }
-    if (counts > s->sample_cap_counts) {
-        s->sample_cap_counts = 0;
-        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_sample_counts[b], &s->h_counts[b], counts));
-        s->sample_cap_counts = counts;
-    }
-    if (energies > s->sample_cap_e) {
-        s->sample_cap_e = 0;
-        for (int b = 0; b < 2; b++) TRY(regrow(&s->d_sample_e[b], &s->h_e[b], energies));
-        if (s->d_sample_m) HIP_TRY(cached_free(s->d_sample_m));
-        s->d_sample_m = nullptr;
-        TRY(dev_alloc(&s->d_sample_m, energies));
-        s->sample_cap_e = energies;
-    }
-    return ISINGMC_OK;
-}
-
-// large output arrays are touched for the first time by the expansion threads: with transparent huge pages the first
-// touch costs one fault per 2 MiB instead of one per 4 KiB (a hint; ignored where THP is off)
-static void madvise_hugepages(void *p, size_t bytes)
-{
-    if (bytes < (size_t(32) << 20)) return;
-    const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + 0x1FFFFF) & ~uintptr_t(0x1FFFFF);
-    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~uintptr_t(0x1FFFFF);
-    if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
-}
-
-static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq, size_t n_samples,
-                             double *energies_out, uint8_t *states_out);
-
-extern "C" int isingmc_run_sampling(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq,
-                                    size_t n_samples, double *energies_out, uint8_t *states_out)
-{
-    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
-    if (!may_use_strips(s) || !(strip_plan(s, thermalization).use || strip_plan(s, sampling_freq).use))
-        return strip_error(run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out));
-    // as run_steps: the call keeps the planes it started from and is repeated without the strip kernel if a launch gives up
-    TRY(use_device(s->g->device));
-    const uint64_t t0 = s->t;
-    TRY(snapshot_take(s));
-    int rc = run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out);
-    if (rc != STRIP_TIMED_OUT) return rc;
-    TRY(snapshot_restore(s));
-    s->t = t0;
-    return strip_error(run_sampling_impl(s, beta, thermalization, sampling_freq, n_samples, energies_out, states_out));
-}
-
-static int run_sampling_impl(isingmc_states *s, double beta, size_t thermalization, size_t sampling_freq, size_t n_samples,
-                             double *energies_out, uint8_t *states_out)
-{
-    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
-    if (sampling_freq == 0) return fail(ISINGMC_ERR_INVALID, "sampling_freq must be positive");
-    if (n_samples && s->R && (!energies_out || !states_out)) return fail(ISINGMC_ERR_INVALID, "NULL output");
-    if (!s->has_betas && !std::isfinite(beta)) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
-    TRY(use_device(s->g->device));
-    const isingmc_graph *g = s->g;
-    const size_t R = s->R, S = n_samples, N = g->nvars;
-    // a uniform beta is installed as per-replica thresholds for the duration of the call: the step
-    // launches then need no per-call host tables and nothing in the loop synchronises
-    struct BetaGuard {
-        isingmc_states *s;
-        bool active;
-        ~BetaGuard() { if (active) (void)isingmc_states_set_betas(s, nullptr); }
-    } guard{s, false};
-    if (!s->has_betas && R) {
-        const std::vector<double> b(R, beta);
-        TRY(set_betas(s, b.data(), /*all_equal=*/true));
-        guard.active = true;
-    }
-    TRY(run_steps(s, thermalization, nullptr, 0, nullptr, nullptr, /*sync=*/false));
-    if (R == 0 || S == 0) {
-        if (R == 0) s->t += S * sampling_freq;
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        return ISINGMC_OK;
-    }
-    const bool counts = s->packed || g->kind == ISINGMC_KIND_LATTICE2D;
-    const size_t words = s->packed ? s->groups * size_t(g->pk.n_pos) : R * g->state_words;
-    const size_t CS = s->packed ? s->pk_slots() : R; // counter pairs per sample
-    // Pipeline over SLABS of samples (<= 64 MiB of packed words each), two in flight: while the host expands
-    // slab j-1 from pinned memory into the caller's bool[R,S,N] array (non-temporal stores, all host threads), the device
-    // runs the sweeps of slab j and a second stream copies finished slabs out.  The expansion to one byte per spin is the
-    // floor of this call (the reference's output format: 8x the packed bytes, host memory bandwidth); the sweeps, the
-    // sample copies and PCIe hide behind it, or it hides behind them when sampling_freq is large.
-    const size_t slab_bytes = size_t(std::max(1, env_int("ISINGMC_SAMPLE_SLAB_BYTES", 64 << 20))); // (tests shrink it)
-    const size_t slab = std::max<size_t>(1, std::min<size_t>(S, slab_bytes / (words * sizeof(uint32_t))));
-    const size_t n_slabs = (S + slab - 1) / slab;
-    TRY(sampling_reserve(s, slab * words, counts ? slab * CS * 2 : 0, counts ? 0 : slab * R));
-    madvise_hugepages(states_out, R * S * N);
-    const auto unpack_slab = [&](size_t j) {
-        const size_t k0 = j * slab, nk = std::min(slab, S - k0), b = j & 1;
-        const uint32_t *h_samples = s->h_samples[b];
-        const unsigned long long *h_counts = s->h_counts[b];
-        const double *h_e = s->h_e[b];
-        parallel_for(nk * R, [&](size_t idx) {
-            const size_t k = idx / R, r = idx % R;
-            uint8_t *out = states_out + (r * S + k0 + k) * N;
-            double energy;
-            if (s->packed) {
-                const size_t sl = r + s->pk_bit0;
-                const uint32_t *w = h_samples + k * words + (sl / 32) * g->pk.n_pos;
-                const uint32_t bit = uint32_t(sl % 32);
-                for (uint64_t i = 0; i < N; i++) out[i] = (w[g->pos[i]] >> bit) & 1u;
-                energy = pk_energy(g, s->rj, h_counts[(k * CS + sl) * 2], h_counts[(k * CS + sl) * 2 + 1]);
-            } else {
-                unpack_state(g, h_samples + k * words + r * g->state_words, out);
-                if (counts) energy = lattice_energy(g, h_counts[(k * R + r) * 2], h_counts[(k * R + r) * 2 + 1]);
-                else energy = h_e[k * R + r] + g->self_energy;
-            }
-            energies_out[r * S + k0 + k] = energy;
-        }, N);
-    };
-    for (size_t j = 0; j < n_slabs; j++) {
-        const size_t k0 = j * slab, nk = std::min(slab, S - k0), b = j & 1;
-        // device slab b is free: its copy-out (slab j-2) was awaited before slab j-2 was expanded, in iteration j-1
-        for (size_t k = 0; k < nk; k++) {
-            TRY(run_steps(s, sampling_freq, nullptr, 0, nullptr, nullptr, /*sync=*/false));
-            HIP_TRY(hipMemcpyAsync(s->d_samples[b] + k * words, s->d_state, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-            TRY(measure_enqueue(s, counts ? s->d_sample_counts[b] + k * CS * 2 : nullptr, counts ? nullptr : s->d_sample_e[b] + k * R,
-                                counts ? nullptr : s->d_sample_m, /*want_up=*/false));
-        }
-        HIP_TRY(hipEventRecord(s->sample_ready[b], s->stream));
-        HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->sample_ready[b], 0));
-        HIP_TRY(hipMemcpyAsync(s->h_samples[b], s->d_samples[b], nk * words * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
-        if (counts) HIP_TRY(hipMemcpyAsync(s->h_counts[b], s->d_sample_counts[b], nk * CS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->copy_stream));
-        else HIP_TRY(hipMemcpyAsync(s->h_e[b], s->d_sample_e[b], nk * R * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-        HIP_TRY(hipEventRecord(s->sample_copied[b], s->copy_stream));
-        if (j >= 1) { // expand the previous slab while the device works on this one
-            HIP_TRY(hipEventSynchronize(s->sample_copied[1 - b]));
-            unpack_slab(j - 1);
-        }
-    }
-    HIP_TRY(hipEventSynchronize(s->sample_copied[(n_slabs - 1) & 1]));
-    unpack_slab(n_slabs - 1);
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    TRY(strip_check(s));
-    return ISINGMC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// on-stream parallel tempering (no host synchronisation inside the sweep / measure / swap loop)
-// ------------------------------------------------------------------------------------------------
-extern "C" int isingmc_states_stream(isingmc_states *s, void **stream_out)
-{
-    if (!s || !stream_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    *stream_out = s->stream;
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_synchronize(isingmc_states *s)
-{
-    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
-    TRY(use_device(s->g->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    return strip_error(strip_check(s));
-}
-
-// where the exchange kernel writes a local slot's acceptance data: {T3, T4} per replica on the lattice path, the RjBeta of
-// the slot's bit position on the real-coupling path
-static uint64_t *pt_thr_local(isingmc_states *s)
-{
-    if (s->packed && s->rj) return reinterpret_cast<uint64_t *>(s->d_rj_betas + s->pk_bit0);
-    if (s->packed) return reinterpret_cast<uint64_t *>(s->d_pk_slot_thr); // pk_bit0 == 0 (checked at attach)
-    return reinterpret_cast<uint64_t *>(s->d_thr);
-}
-
-// bit-sliced packed path: the groups' threshold tables follow the slots' new thresholds (enqueue only)
-static int pt_after_swap(isingmc_states *s)
-{
-    if (s->packed && !s->rj && s->R) {
-        hipLaunchKernelGGL(pk_tables_from_slots_kernel, dim3(unsigned(s->groups)), dim3(64), 0, s->stream, s->d_pk_slot_thr, uint32_t(s->R), s->d_tab);
-        HIP_TRY(hipGetLastError());
-    }
-    return ISINGMC_OK;
-}
-
-// why this container cannot take an on-stream ladder of that geometry ("" when it can): no side effects
-static std::string pt_attach_obstacle(const isingmc_states *s, size_t n_rungs, size_t slot_offset, size_t slots_per_rank, size_t world_size)
-{
-    if (s->pt_attached) return "a ladder is already attached";
-    const bool pk_ladder = s->packed && !s->rj;
-    if (!s->packed && (s->g->kind != ISINGMC_KIND_LATTICE2D || s->g->mc_mode != MC_NONE))
-        return "on-stream tempering is implemented for periodic, field-free lattices and for the replica-packed "
-               "paths (use the host swap step)";
-    // the replicas of a bit-sliced group number their ties together: a shard must hold whole groups (distributed.block_size aligns them)
-    if (pk_ladder && (s->pk_bit0 != 0 || ((s->first + s->R) % 32 != 0 && s->first + s->R != s->n_total)))
-        return "a tempering shard on the replica-packed path must start and end on multiples of 32 slots";
-    if (slot_offset + s->R > n_rungs || s->R > slots_per_rank || slots_per_rank * world_size < n_rungs || n_rungs >= 0xFFFFFFFFull)
-        return "ladder / shard geometry mismatch";
-    return "";
-}
-
-extern "C" int isingmc_pt_can_attach(const isingmc_states *s, size_t n_rungs, size_t slot_offset, size_t slots_per_rank,
-                                     size_t world_size, int *ok_out)
-{
-    if (!s || !ok_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    const std::string why = pt_attach_obstacle(s, n_rungs, slot_offset, slots_per_rank, world_size);
-    *ok_out = why.empty() ? 1 : 0;
-    if (!why.empty()) g_last_error = why; // (informational: the call itself succeeded)
-    return ISINGMC_OK;
-}
-
-// the ladder's device buffers go back; the container keeps its configurations and timestep and takes uniform betas again
-extern "C" int isingmc_pt_detach(isingmc_states *s)
-{
-    if (!s) return fail(ISINGMC_ERR_INVALID, "NULL states");
-    if (!s->pt_attached) return ISINGMC_OK;
-    TRY(use_device(s->g->device));
-    HIP_TRY(hipStreamSynchronize(s->stream)); // enqueued rounds may still read the ladder
-    TRY(strip_error(strip_check(s)));
-    for (void **p : {(void **)&s->d_pt_ladder, (void **)&s->d_pt_local, (void **)&s->d_pt_all, (void **)&s->d_pt_ladder_thr,
-                     (void **)&s->d_pt_perm, (void **)&s->d_pt_counters, (void **)&s->d_pt_mail, (void **)&s->d_pt_round_counts,
-                     (void **)&s->d_pt_perm2}) {
-        if (*p) (void)cached_free(*p);
-        *p = nullptr;
-    }
-    s->pt = PtDev{};
-    s->pt_attached = false;
-    s->has_betas = false;
-    s->betas.clear();
-    s->meas_fresh = false;
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_pt_attach(isingmc_states *s, const double *ladder_betas, size_t n_rungs, size_t slot_offset,
-                                 size_t slots_per_rank, size_t world_size, uint64_t seed)
-{
-    if (!s || !ladder_betas) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    {
-        const std::string why = pt_attach_obstacle(s, n_rungs, slot_offset, slots_per_rank, world_size);
-        if (!why.empty()) return fail(ISINGMC_ERR_INVALID, why);
-    }
-    const bool rj_ladder = s->packed && s->rj, pk_ladder = s->packed && !s->rj;
-    for (size_t i = 0; i < n_rungs; i++)
-        if (!std::isfinite(ladder_betas[i])) return fail(ISINGMC_ERR_INVALID, "beta must be finite");
-    TRY(use_device(s->g->device));
-    const isingmc_graph *g = s->g;
-    const bool lattice = g->kind == ISINGMC_KIND_LATTICE2D;
-    TRY(dev_alloc(&s->d_pt_ladder, n_rungs));
-    TRY(dev_alloc(&s->d_pt_perm, n_rungs));
-    TRY(dev_alloc(&s->d_pt_local, slots_per_rank));
-    TRY(dev_alloc(&s->d_pt_all, slots_per_rank * world_size));
-    TRY(dev_alloc(&s->d_pt_counters, 2));
-    std::vector<uint32_t> perm(n_rungs);
-    for (size_t i = 0; i < n_rungs; i++) perm[i] = uint32_t(i);
-    HIP_TRY(hipMemcpy(s->d_pt_ladder, ladder_betas, n_rungs * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_pt_perm, perm.data(), n_rungs * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(s->d_pt_counters, 0, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(s->d_pt_local, 0, slots_per_rank * sizeof(double)));
-    HIP_TRY(hipMemset(s->d_pt_all, 0, slots_per_rank * world_size * sizeof(double)));
-    if (rj_ladder) { // acceptance scales per rung (host arithmetic: the bits of isingmc_states_set_betas)
-        std::vector<uint64_t> thr(n_rungs);
-        for (size_t i = 0; i < n_rungs; i++) {
-            RjBeta b;
-            rj_beta(ladder_betas[i], g->rj_k, &b.shift, &b.mant);
-            std::memcpy(&thr[i], &b, sizeof b);
-        }
-        TRY(dev_alloc(&s->d_pt_ladder_thr, n_rungs));
-        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        if (!s->d_rj_betas) TRY(dev_alloc(&s->d_rj_betas, 32 * s->groups));
-        std::vector<RjBeta> init(32 * s->groups, RjBeta{31u, 0xFFFFFFFFu}); // bits this shard does not own: accept-all, nobody reads them
-        HIP_TRY(hipMemcpy(s->d_rj_betas, init.data(), init.size() * sizeof(RjBeta), hipMemcpyHostToDevice));
-    }
-    if (pk_ladder) { // T_m per rung, m = 1 .. PK_MAX_DEG: the values pk_fill_table puts into the host-built tables
-        std::vector<uint64_t> thr(size_t(PK_MAX_DEG) * n_rungs);
-        for (size_t i = 0; i < n_rungs; i++)
-            for (uint32_t m = 1; m <= uint32_t(PK_MAX_DEG); m++) thr[i * PK_MAX_DEG + m - 1] = threshold_fixed(ladder_betas[i], 2.0 * g->jabs * double(m));
-        TRY(dev_alloc(&s->d_pt_ladder_thr, thr.size()));
-        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        if (!s->d_pk_slot_thr) TRY(dev_alloc(&s->d_pk_slot_thr, size_t(32) * s->groups * PK_MAX_DEG));
-        HIP_TRY(hipMemset(s->d_pk_slot_thr, 0, size_t(32) * s->groups * PK_MAX_DEG * sizeof(unsigned long long)));
-        if (!s->d_tab) TRY(dev_alloc(&s->d_tab, s->groups * PK_TAB_WORDS));
-    }
-    if (lattice) { // thresholds per rung from the host's exp: bit-identical to isingmc_states_set_betas
-        std::vector<uint64_t> thr(2 * n_rungs);
-        for (size_t i = 0; i < n_rungs; i++) {
-            const LatThr t = lattice_thresholds(ladder_betas[i], g->jabs);
-            thr[2 * i] = t.T3;
-            thr[2 * i + 1] = t.T4;
-        }
-        TRY(dev_alloc(&s->d_pt_ladder_thr, 2 * n_rungs));
-        HIP_TRY(hipMemcpy(s->d_pt_ladder_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    }
-    s->pt = PtDev{s->d_pt_ladder, s->d_pt_ladder_thr, rj_ladder ? 1u : pk_ladder ? uint32_t(PK_MAX_DEG) : 2u, s->d_pt_perm, s->d_pt_all, s->d_pt_counters, uint32_t(n_rungs),
-                  uint32_t(slot_offset), uint32_t(s->R), uint32_t(seed), uint32_t(seed >> 32)};
-    s->pt_per = slots_per_rank;
-    s->pt_world = world_size;
-    s->betas.assign(s->R, 0.0);
-    s->has_betas = true;
-    s->pt_attached = true;
-    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 1u);
-    HIP_TRY(hipGetLastError());
-    TRY(pt_after_swap(s));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_pt_buffers(isingmc_states *s, void **d_local_out, void **d_all_out, size_t *per_rank_out)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    if (d_local_out) *d_local_out = s->d_pt_local;
-    if (d_all_out) *d_all_out = s->d_pt_all;
-    if (per_rank_out) *per_rank_out = s->pt_per;
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_pt_time_steps(isingmc_states *s, size_t timesteps)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    // the strip kernel measures the final configurations itself: isingmc_pt_measure then needs no pass over the planes
-    return run_steps(s, timesteps, nullptr, 0, nullptr, nullptr, /*sync=*/false,
-                     /*final_energies=*/s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
-}
-
-// The loop of tempering.rs:177-194 { timesteps(swap_every); parallel_tempering_step } for `timesteps` sweeps in ONE library
-// call (enqueue only), with an exchange round after every swap_every-th sweep.  Single rank + strip geometry: one persistent
-// launch whose strips exchange temperatures pair by pair through rung-indexed mailboxes (StripLadder), only the last
-// round at a kernel boundary; otherwise the per-round sequence of the calls above.  Ranks > 1 must interleave their
-// all-gather and therefore keep calling isingmc_pt_time_steps / _measure / _swap themselves.
-extern "C" int isingmc_pt_run(isingmc_states *s, size_t timesteps, size_t swap_every)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    if (swap_every == 0) return fail(ISINGMC_ERR_INVALID, "swap_every must be positive");
-    if (s->pt_world != 1) return fail(ISINGMC_ERR_INVALID, "isingmc_pt_run is for a single rank: the all-gather of a sharded ladder sits between measure and swap");
-    TRY(use_device(s->g->device));
-    const isingmc_graph *g = s->g;
-    const size_t rounds = timesteps / swap_every, tail = timesteps % swap_every;
-    const StripPlan P = s->R ? strip_plan(s, rounds * swap_every, /*ladder=*/true) : StripPlan{};
-    const bool in_kernel = P.use && P.replicas_per_pass >= s->R && rounds >= 2 && rounds * swap_every <= 65536 &&
-                           s->R == s->pt.n_rungs && env_int("ISINGMC_PT_IN_KERNEL", 1) != 0;
-    if (in_kernel) {
-        const size_t R = s->R, nk = rounds * swap_every;
-        if (!s->d_pt_mail) {
-            TRY(dev_alloc(&s->d_pt_mail, 4 * R));
-            TRY(dev_alloc(&s->d_pt_round_counts, 2 * R));
-            TRY(dev_alloc(&s->d_pt_perm2, R));
-            HIP_TRY(hipMemsetAsync(s->d_pt_mail, 0, 4 * R * sizeof(unsigned long long), s->stream));
-            HIP_TRY(hipMemsetAsync(s->d_pt_round_counts, 0, 2 * R * sizeof(unsigned long long), s->stream));
-        }
-        // the number of the first round is on the device (exchange rounds never synchronise with the host): read it once here
-        unsigned long long c[2];
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
-        const StripLadder lad{s->d_pt_ladder, reinterpret_cast<const unsigned long long *>(s->d_pt_ladder_thr), s->d_pt_perm, s->d_pt_perm2,
-                              s->d_pt_mail, s->d_pt_round_counts, s->d_pt_counters, c[0], uint32_t(R), uint32_t(swap_every), s->pt.seed_lo,
-                              s->pt.seed_hi, g->jabs, 2ll * (long long)g->nvars};
-        s->meas_fresh = false;
-        TRY(launch_strip(s, P, 0, R, nk, nullptr, 0, nullptr, s->d_pt_all + s->pt.slot_offset, &lad));
-        s->strip_epoch += uint32_t(2 * nk);
-        s->t += nk;
-        s->meas_fresh = true; // the launch wrote the final energies
-        HIP_TRY(hipMemcpyAsync(s->d_pt_perm, s->d_pt_perm2, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-        TRY(isingmc_pt_measure(s));
-        TRY(isingmc_pt_swap(s)); // the last round of the block, at the kernel boundary (it also relabels d_thr / d_beta)
-    } else {
-        for (size_t k = 0; k < rounds; k++) {
-            TRY(isingmc_pt_time_steps(s, swap_every));
-            TRY(isingmc_pt_measure(s));
-            TRY(isingmc_pt_swap(s));
-        }
-    }
-    if (tail) TRY(isingmc_pt_time_steps(s, tail));
-    return ISINGMC_OK;
-}
-
-// enqueue: energies of the local slots -> the local send buffer (and straight into the gathered
-// buffer when there is a single rank)
-extern "C" int isingmc_pt_measure(isingmc_states *s)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    TRY(use_device(s->g->device));
-    const isingmc_graph *g = s->g;
-    const size_t R = s->R;
-    if (R == 0) return ISINGMC_OK;
-    if (g->kind == ISINGMC_KIND_LATTICE2D) {
-        // three launches per round: the conversion kernel leaves the counters zeroed for the next round and, on
-        // a single rank, writes straight into the gathered array (no memset, no device-to-device copy)
-        if (s->meas_fresh) { // the last strip launch of isingmc_pt_time_steps has already written these energies
-            s->meas_fresh = false;
-            return ISINGMC_OK;
-        }
-        if (!s->meas_zero) HIP_TRY(hipMemsetAsync(s->d_meas, 0, 2 * R * sizeof(unsigned long long), s->stream));
-        LAT_DISPATCH(launch_lat_measure, s, s->d_meas, size_t(2));
-        hipLaunchKernelGGL(lat_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas,
-                           uint32_t(R), g->jabs, 2ll * (long long)g->nvars,
-                           s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
-        s->meas_zero = true;
-    } else if (s->packed && !s->rj) {
-        TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
-        s->meas_zero = false;
-        hipLaunchKernelGGL(pk_energy_from_counts_kernel, dim3(unsigned((R + 255) / 256)), dim3(256), 0, s->stream, s->d_meas, uint32_t(s->pk_bit0),
-                           uint32_t(R), g->jabs, double(int64_t(g->n_directed / 2)), g->self_energy,
-                           s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local);
-    } else if (s->packed && s->rj) {
-        TRY(measure_enqueue(s, s->d_meas, nullptr, nullptr, /*want_up=*/false));
-        s->meas_zero = false;
-        HIP_TRY(rj_launch_energy_from_counts(s->stream, s->d_meas, uint32_t(s->pk_bit0), uint32_t(R), g->rj_k_energy, g->self_energy,
-                                             s->pt_world == 1 ? s->d_pt_all + s->pt.slot_offset : s->d_pt_local));
-    } else {
-        return fail(ISINGMC_ERR_INVALID, "on-stream tempering is implemented for the lattice path and the real-coupling path; use the host swap step");
-    }
-    HIP_TRY(hipGetLastError());
-    return ISINGMC_OK;
-}
-
-// enqueue: one exchange round from the gathered energies; relabels the local slots
-extern "C" int isingmc_pt_swap(isingmc_states *s)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    TRY(use_device(s->g->device));
-    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(1024), 0, s->stream, s->pt, pt_thr_local(s), s->packed ? nullptr : s->d_beta, 0u);
-    HIP_TRY(hipGetLastError());
-    return pt_after_swap(s);
-}
-
-// synchronises; perm_out: uint32[n_rungs] (rung -> slot)
-extern "C" int isingmc_pt_state(isingmc_states *s, uint32_t *perm_out, uint64_t *round_out, uint64_t *swaps_out)
-{
-    if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "no ladder attached");
-    TRY(use_device(s->g->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    TRY(strip_error(strip_check(s)));
-    unsigned long long c[2];
-    HIP_TRY(hipMemcpy(c, s->d_pt_counters, sizeof c, hipMemcpyDeviceToHost));
-    if (perm_out) HIP_TRY(hipMemcpy(perm_out, s->d_pt_perm, s->pt.n_rungs * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (round_out) *round_out = c[0];
-    if (swaps_out) *swaps_out = c[1];
-    return ISINGMC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// measurement hook: the shader clock the chip holds WHILE the sweep kernels run (bench.py reports it next
-// to the vector-ALU bound).  One wave on a side stream stamps s_memtime (shader cycles) and s_memrealtime
-// (100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6) around a sleep loop of `probe_ms`, while `timesteps`
-// sweeps run on the engine's stream.  The probe's exit condition is the constant-rate counter: every wave leaves.
-// ------------------------------------------------------------------------------------------------
-__global__ void clock_probe_kernel(unsigned long long *out, const unsigned long long realtime_ticks)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
-    unsigned long long r1;
-    do {
-        __builtin_amdgcn_s_sleep(100);
-        r1 = __builtin_amdgcn_s_memrealtime();
-    } while (r1 - r0 < realtime_ticks);
-    out[0] = __builtin_amdgcn_s_memtime() - c0;
-    out[1] = r1 - r0;
-}
-
-extern "C" int isingmc_debug_shader_clock(isingmc_states *s, size_t timesteps, double beta, double probe_ms, double *ghz_out)
-{
-    if (!s || !ghz_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
-    if (!(probe_ms > 0.0) || probe_ms > 100.0) return fail(ISINGMC_ERR_INVALID, "probe_ms must be in (0, 100]");
-    TRY(use_device(s->g->device));
-    DeviceScratch scratch(s->stream);
-    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
-    TRY(scratch.alloc(&d_out, 2));
-    struct Side { // a stream of its own: the replica lanes carry sweeps
-        hipStream_t st = nullptr;
-        ~Side() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
-    } side_owner;
-    HIP_TRY(hipStreamCreateWithFlags(&side_owner.st, hipStreamNonBlocking));
-    hipStream_t side = side_owner.st;
-    // the sweeps first (they ramp the chip up), then the probe beside them; both are awaited
-    int rc = run_steps(s, timesteps / 4, &beta, 0, nullptr, nullptr, /*sync=*/false);
-    if (rc != ISINGMC_OK) return rc;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, side, d_out, (unsigned long long)(probe_ms * 1e5));
-    HIP_TRY(hipGetLastError());
-    rc = run_steps(s, timesteps - timesteps / 4, &beta, 0, nullptr, nullptr, /*sync=*/true);
-    HIP_TRY(hipStreamSynchronize(side));
-    if (rc != ISINGMC_OK) return rc;
-    HIP_TRY(hipMemcpy(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost));
-    *ghz_out = h_out[1] ? double(h_out[0]) / double(h_out[1]) * 0.1 : 0.0; // cycles per 10 ns tick -> GHz
-    return ISINGMC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// In-process ladder across several devices: the shards of ONE beta ladder, each an isingmc_states on its
-// own device with the ladder attached (isingmc_pt_attach, world_size = the number of shards), driven from ONE host thread.
-// Between measure and swap every shard needs every shard's energies -- the swap step of tempering.rs:191-194 -- :
-//   * RCCL: ncclAllGather of the `local` buffers into the `all` buffers, one communicator per shard (ncclCommInitAll), enqueued on
-//     each shard's engine stream inside ncclGroupStart / ncclGroupEnd.  librccl.so is resolved with dlopen at group creation:
-//     a single-GPU user of libisingmc.so needs no RCCL at all, and a Rust / pyo3 host needs no NCCL binding of its own.
-//   * device copies (the shards share a device, RCCL is not installed, or ISINGMC_PT_GROUP_BACKEND=copy): the same gather as
-//     events + hipMemcpyPeerAsync on the engines' streams.
-// Both leave the same bytes in every `all` buffer; nothing in the loop waits on the host.
-// ------------------------------------------------------------------------------------------------
-#include <dlfcn.h>
-
-namespace {
-struct Rccl {
-    void *handle = nullptr;
-    int (*CommInitAll)(void **, int, const int *) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    bool ok() const { return handle && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
-};
-constexpr int RCCL_FLOAT64 = 8; // ncclFloat64 (rccl.h)
-
-Rccl &rccl()
-{
-    static Rccl *r = [] {
-        auto *x = new Rccl;
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            x->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (x->handle) break;
-        }
-        if (x->handle) {
-            x->CommInitAll = reinterpret_cast<decltype(x->CommInitAll)>(dlsym(x->handle, "ncclCommInitAll"));
-            x->CommDestroy = reinterpret_cast<decltype(x->CommDestroy)>(dlsym(x->handle, "ncclCommDestroy"));
-            x->AllGather = reinterpret_cast<decltype(x->AllGather)>(dlsym(x->handle, "ncclAllGather"));
-            x->GroupStart = reinterpret_cast<decltype(x->GroupStart)>(dlsym(x->handle, "ncclGroupStart"));
-            x->GroupEnd = reinterpret_cast<decltype(x->GroupEnd)>(dlsym(x->handle, "ncclGroupEnd"));
-            x->GetErrorString = reinterpret_cast<decltype(x->GetErrorString)>(dlsym(x->handle, "ncclGetErrorString"));
-        }
-        return x;
-    }();
-    return *r;
-}
-} // namespace
-
-struct isingmc_pt_group {
-    std::vector<isingmc_states *> shards;
-    std::vector<void *> comms;        // RCCL communicators, one per shard (empty: device copies)
-    std::vector<hipEvent_t> measured; // per shard: its energies are in its `local` buffer
-    size_t per = 0;
-
-    ~isingmc_pt_group()
-    {
-        for (size_t k = 0; k < shards.size(); k++) {
-            (void)hipSetDevice(shards[k]->g->device);
-            (void)hipStreamSynchronize(shards[k]->stream);
-            if (k < comms.size() && comms[k]) (void)rccl().CommDestroy(comms[k]);
-            if (k < measured.size() && measured[k]) (void)hipEventDestroy(measured[k]);
-        }
-    }
-};
-
-static int rccl_fail(int rc, const char *what)
-{
-    const char *msg = rccl().GetErrorString ? rccl().GetErrorString(rc) : "?";
-    return fail(ISINGMC_ERR_HIP, std::string(what) + ": " + msg);
-}
-
-extern "C" int isingmc_pt_group_create(isingmc_states **shards, size_t n_shards, int backend, isingmc_pt_group **group_out)
-{
-    if (!shards || !group_out || n_shards == 0) return fail(ISINGMC_ERR_INVALID, "NULL argument / no shards");
-    *group_out = nullptr;
-    size_t offset = 0;
-    std::vector<int> devices;
-    bool distinct = true;
-    for (size_t k = 0; k < n_shards; k++) {
-        const isingmc_states *s = shards[k];
-        if (!s || !s->pt_attached) return fail(ISINGMC_ERR_INVALID, "every shard needs an attached ladder (isingmc_pt_attach)");
-        if (s->pt_world != n_shards || s->pt_per != shards[0]->pt_per || s->pt.n_rungs != shards[0]->pt.n_rungs ||
-            s->pt.seed_lo != shards[0]->pt.seed_lo || s->pt.seed_hi != shards[0]->pt.seed_hi)
-            return fail(ISINGMC_ERR_INVALID, "the shards are not attached to one ladder (world size, slots per rank, rungs, seed)");
-        if (s->pt.slot_offset != offset || s->pt.slot_offset != k * s->pt_per)
-            return fail(ISINGMC_ERR_INVALID, "shard k must own the slots from k * slots_per_rank on, in rank order");
-        offset += s->R;
-        for (int d : devices) distinct &= d != s->g->device;
-        devices.push_back(s->g->device);
-    }
-    if (offset != shards[0]->pt.n_rungs) return fail(ISINGMC_ERR_INVALID, "the shards do not cover the ladder");
-    auto grp = std::make_unique<isingmc_pt_group>();
-    grp->shards.assign(shards, shards + n_shards);
-    grp->per = shards[0]->pt_per;
-    grp->measured.assign(n_shards, nullptr);
-    for (size_t k = 0; k < n_shards; k++) {
-        TRY(use_device(devices[k]));
-        HIP_TRY(hipEventCreateWithFlags(&grp->measured[k], hipEventDisableTiming));
-    }
-    // backend: 0 = RCCL when the devices are distinct (or there is one shard) and librccl.so resolves, else device copies;
-    // 1 = RCCL or fail; 2 = device copies
-    const char *env = std::getenv("ISINGMC_PT_GROUP_BACKEND");
-    if (backend == 0 && env) backend = std::string(env) == "rccl" ? 1 : std::string(env) == "copy" ? 2 : 0;
-    const bool want_rccl = backend == 1 || (backend == 0 && distinct && rccl().ok());
-    if (backend == 1 && !rccl().ok()) return fail(ISINGMC_ERR_HIP, "librccl.so could not be loaded (dlopen)");
-    if (backend == 1 && !distinct) return fail(ISINGMC_ERR_INVALID, "RCCL needs one device per shard (ncclCommInitAll refuses duplicates)");
-    if (want_rccl) {
-        grp->comms.assign(n_shards, nullptr);
-        const int rc = rccl().CommInitAll(grp->comms.data(), int(n_shards), devices.data());
-        if (rc != 0) {
-            grp->comms.clear();
-            return rccl_fail(rc, "ncclCommInitAll");
-        }
-    }
-    *group_out = grp.release();
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_pt_group_backend(const isingmc_pt_group *grp)
-{
-    return grp && !grp->comms.empty() ? 1 : 2;
-}
-
-// enqueue: every shard's `local` energies -> every shard's `all` buffer (rank-major, slots_per_rank each)
-extern "C" int isingmc_pt_group_allgather(isingmc_pt_group *grp)
-{
-    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
-    const size_t n = grp->shards.size();
-    if (!grp->comms.empty()) {
-        int rc = rccl().GroupStart();
-        if (rc != 0) return rccl_fail(rc, "ncclGroupStart");
-        for (size_t k = 0; k < n && rc == 0; k++) {
-            isingmc_states *s = grp->shards[k];
-            rc = rccl().AllGather(s->d_pt_local, s->d_pt_all, grp->per, RCCL_FLOAT64, grp->comms[k], s->stream);
-        }
-        const int rc2 = rccl().GroupEnd();
-        if (rc != 0) return rccl_fail(rc, "ncclAllGather");
-        if (rc2 != 0) return rccl_fail(rc2, "ncclGroupEnd");
-        return ISINGMC_OK;
-    }
-    for (size_t j = 0; j < n; j++) { // shard j's measurement is complete ...
-        TRY(use_device(grp->shards[j]->g->device));
-        HIP_TRY(hipEventRecord(grp->measured[j], grp->shards[j]->stream));
-    }
-    for (size_t k = 0; k < n; k++) { // ... before any shard k copies it
-        isingmc_states *s = grp->shards[k];
-        TRY(use_device(s->g->device));
-        for (size_t j = 0; j < n; j++) {
-            const isingmc_states *src = grp->shards[j];
-            if (j != k) HIP_TRY(hipStreamWaitEvent(s->stream, grp->measured[j], 0));
-            HIP_TRY(hipMemcpyPeerAsync(s->d_pt_all + j * grp->per, s->g->device, src->d_pt_local, src->g->device, grp->per * sizeof(double), s->stream));
-        }
-    }
-    // a shard's `local` buffer is overwritten by its next measurement: that must wait for the copies the OTHER shards made of it
-    for (size_t k = 0; k < n; k++) {
-        TRY(use_device(grp->shards[k]->g->device));
-        HIP_TRY(hipEventRecord(grp->measured[k], grp->shards[k]->stream));
-    }
-    for (size_t j = 0; j < n; j++) {
-        TRY(use_device(grp->shards[j]->g->device));
-        for (size_t k = 0; k < n; k++)
-            if (k != j) HIP_TRY(hipStreamWaitEvent(grp->shards[j]->stream, grp->measured[k], 0));
-    }
-    return ISINGMC_OK;
-}
-
-// enqueue: the loop of tempering.rs:177-194 over the whole ladder -- `timesteps` sweeps on every shard with an exchange round
-// (measure, all-gather, swap) after every swap_every-th one
-extern "C" int isingmc_pt_group_run(isingmc_pt_group *grp, size_t timesteps, size_t swap_every)
-{
-    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
-    if (swap_every == 0) return fail(ISINGMC_ERR_INVALID, "swap_every must be positive");
-    for (size_t done = 0; done < timesteps;) {
-        const size_t b = std::min(swap_every, timesteps - done);
-        for (isingmc_states *s : grp->shards) TRY(isingmc_pt_time_steps(s, b));
-        done += b;
-        if (b == swap_every) {
-            for (isingmc_states *s : grp->shards) TRY(isingmc_pt_measure(s));
-            TRY(isingmc_pt_group_allgather(grp));
-            for (isingmc_states *s : grp->shards) TRY(isingmc_pt_swap(s));
-        }
-    }
-    return ISINGMC_OK;
-}
-
-extern "C" int isingmc_pt_group_synchronize(isingmc_pt_group *grp)
-{
-    if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
-    for (isingmc_states *s : grp->shards) TRY(isingmc_synchronize(s));
-    return ISINGMC_OK;
-}
-
-extern "C" void isingmc_pt_group_destroy(isingmc_pt_group *grp) { delete grp; }

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t pk_match(uint32_t c0, uint32_t c1, uint32_t 
 }
 
 // one colour class of one timestep; blockIdx.y = replica group
-__global__ __launch_bounds__(256, 8) void pk_sweep_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+__attribute__((unused)) static __global__ __launch_bounds__(256, 8) void pk_sweep_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
                                                        const uint32_t class_begin, const uint32_t class_end,
                                                        const uint64_t t, const uint2 *__restrict__ group_keys,
                                                        const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 8) void pk_sweep_kernel(uint32_t *__restrict__
 
 // random start: position p is word q = (p & 255) >> 6 of its quad (leader p - 64 q):
 // word = Philox(group key, (0, leader, 0, "PKIN"))[q]; padding positions 0
-__global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
                                                       const uint2 *__restrict__ group_keys, const uint32_t first_group)
 {
     const uint32_t g = first_group + blockIdx.y;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void pk_init_kernel(uint32_t *__restrict__ sta
 
 // the random start of ONE replica bit of a group (real-coupling path: a replica appended to a partly used group starts from
 // its random start -- the bits a container does not own are not simulated there, see rj_sweep_kernel PARTIAL)
-__global__ __launch_bounds__(256) void pk_init_replica_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void pk_init_replica_kernel(uint32_t *__restrict__ state, const PkGraphDev G,
                                                               const uint2 *__restrict__ group_keys, const uint32_t g, const uint32_t bit)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void bs_add(uint32_t (&S)[K], const uint32_t (&x)[K2]
 // sat_end / sat_scale: on a 2-coloured (bipartite) graph every bond joins class 0 to class 1, so the bonds are counted from
 // the class-0 positions only (sat_end = the end of class 0) and doubled (sat_scale = 2) into the same directed total -- half
 // the neighbour gathers; otherwise sat_end = n_pos, sat_scale = 1.
-__global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restrict__ state, const PkGraphDev G,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restrict__ state, const PkGraphDev G,
                                                          unsigned long long *__restrict__ out, const uint32_t n_replicas,
                                                          const uint32_t pos_per_thread, const uint32_t sat_end, const uint32_t sat_scale)
 {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void pk_measure_kernel(const uint32_t *__restr
 }
 
 // write one replica's spins (bits[] packed by position, 32 positions per word) into bit `bit` of group g
-__global__ __launch_bounds__(256) void pk_set_replica_kernel(uint32_t *__restrict__ state, const uint32_t n_pos,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void pk_set_replica_kernel(uint32_t *__restrict__ state, const uint32_t n_pos,
                                                              const uint32_t *__restrict__ bits, const uint32_t g,
                                                              const uint32_t bit)
 {

@@ -189,14 +189,16 @@ def test_strip_timeout_is_recovered(capi, oracle, exact, monkeypatch):
     np.testing.assert_array_equal(s2, ref_s)
     np.testing.assert_array_equal(st.packed(), ref.packed())
     # the same hook under the sampling call's own guard
-    st2 = capi.States(g, seeds)
+    st2 = capi.States(g, seeds)                      # (the switches are read when a container is created ...)
     ref2 = capi.States(g, seeds)
-    monkeypatch.setenv("ISINGMC_STRIP_TEST_FAIL_ONCE", "0")
-    monkeypatch.setenv("ISINGMC_STRIP", "0")
+    ref2.set_option("strip_test_fail_once", 0)       # (... and changed per container: two objects of one process on different paths)
+    ref2.set_option("STRIP", 0)
     e_ref, s_ref = ref2.run_sampling(0.45, 4, 3, 2)
-    monkeypatch.setenv("ISINGMC_STRIP", "1")
-    monkeypatch.setenv("ISINGMC_STRIP_TEST_FAIL_ONCE", "1")
     e_got, s_got = st2.run_sampling(0.45, 4, 3, 2)
+    with pytest.raises(ValueError):
+        st2.set_option("force_packed", 1)            # the kernel family is fixed at creation
+    with pytest.raises(ValueError):
+        st2.set_option("no_such_switch", 1)
     np.testing.assert_array_equal(e_got, e_ref)
     np.testing.assert_array_equal(s_got, s_ref)
     lat = oracle.Lat(W, H)
