@@ -421,6 +421,12 @@ extern "C" int isingmc_pt_group_allgather(isingmc_pt_group *grp)
 {
     if (!grp) return fail(ISINGMC_ERR_INVALID, "NULL group");
     const size_t n = grp->shards.size();
+    if (n == 1) { // a single rank measures straight into its `all` buffer (isingmc_pt_measure): the send buffer follows it, so that
+                  // the collective below -- a real communicator of one rank: what a one-GPU box can execute of RCCL -- moves the same bytes
+        isingmc_states *s = grp->shards[0];
+        TRY(use_device(s->g->device));
+        HIP_TRY(hipMemcpyAsync(s->d_pt_local, s->d_pt_all, grp->per * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    }
     if (!grp->comms.empty()) {
         int rc = rccl().GroupStart();
         if (rc != 0) return rccl_fail(rc, "ncclGroupStart");
