@@ -214,9 +214,11 @@ void check_case(Rng &r, const Edges &e, bool expect_lattice, bool known_lattice_
     if (bias_kind == 2) { bias.resize(n); for (auto &h : bias) h = r.unit() - 0.5; }
     if (bias_kind == 3) { bias.assign(n, 0.0); bias[r.below(n)] = 1e9; }
     const RjQuant Q = rj_quantise(A, n, bias.empty() ? nullptr : bias.data());
-    CHECK(Q.jq.size() == A.w.size() && Q.hq.size() == n);
+    CHECK(Q.jq.size() == A.w.size() && Q.hq.size() == n && Q.dshift.size() == n);
+    CHECK(Q.jhi.size() == A.w.size() && Q.jlo.size() == A.w.size() && Q.hhi.size() == n && Q.hlo.size() == n);
     uint32_t maxdeg = 0;
     double fmax = 0.0;
+    bool any_heavy = false;
     for (size_t i = 0; i < n; i++) {
         int64_t total = std::llabs(int64_t(Q.hq[i]));
         double f = bias.empty() ? 0.0 : std::fabs(bias[i]);
@@ -224,19 +226,35 @@ void check_case(Rng &r, const Edges &e, bool expect_lattice, bool known_lattice_
             total += std::llabs(int64_t(Q.jq[q]));
             f += std::fabs(A.w[q]);
         }
-        // |X| <= sum of the rounded magnitudes: each rounds by at most 1/2, Fmax 2^-k < 2^30
+        // |X| <= sum of the rounded magnitudes: each rounds by at most 1/2, F_i 2^-(k + d_i) < 2^30
         CHECK(total <= (int64_t(1) << 30) + int64_t(A.ptr[i + 1] - A.ptr[i] + 1) / 2 + 1);
+        CHECK(Q.dshift[i] <= 31);
+        any_heavy |= Q.dshift[i] != 0;
+        // a site sees its bonds and its bias to half a quantum of ITS scale 2^(k + d_i) (d_i < 31: the shift is not capped)
+        if (Q.dshift[i] < 31) {
+            const int ki = Q.k + int(Q.dshift[i]);
+            for (uint64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) CHECK(std::fabs(std::ldexp(A.w[q], -ki) - double(Q.jq[q])) <= 0.5);
+            if (!bias.empty()) CHECK(std::fabs(std::ldexp(bias[i], -ki) - double(Q.hq[i])) <= 0.5);
+            if (f > 0.0 && Q.dshift[i] > 0) CHECK(std::ldexp(f, -ki) >= double(1 << 29) && std::ldexp(f, -ki) < double(int64_t(1) << 30));
+        }
         maxdeg = std::max<uint32_t>(maxdeg, uint32_t(A.ptr[i + 1] - A.ptr[i]));
         fmax = std::max(fmax, f);
     }
-    CHECK(Q.max_degree == maxdeg);
-    if (Q.eligible) {
-        CHECK(maxdeg <= 15 && fmax > 0.0);
-        CHECK(std::ldexp(fmax, -Q.k) >= double(1 << 29) && std::ldexp(fmax, -Q.k) < double(int64_t(1) << 30));
-        for (size_t q = 0; q < A.w.size(); q++) // the same integer on both ends of a bond, rounding error <= 1/2
-            CHECK(std::fabs(std::ldexp(A.w[q], -Q.k) - double(Q.jq[q])) <= 0.5);
+    CHECK(Q.max_degree == maxdeg && Q.heavy == any_heavy);
+    if (Q.eligible) CHECK(maxdeg <= 31 && fmax > 0.0);
+    if (fmax > 0.0) { // the graph's quantum never exceeds 2^-30 of the largest local field; the two energy levels reproduce every term
+        CHECK(std::ldexp(fmax, -Q.k) >= double(1 << 29));
+        CHECK(std::ldexp(fmax, -Q.k_energy) >= double(1 << 28) && std::ldexp(fmax, -Q.k_energy) < double(1 << 29));
+        const double tol = std::ldexp(1.0, Q.k_energy - 25) * (1.0 + 1e-9);
+        for (size_t q = 0; q < A.w.size(); q++) {
+            CHECK(std::abs(Q.jlo[q]) <= (1 << 23));
+            CHECK(std::fabs(std::ldexp(double(Q.jhi[q]), Q.k_energy) + std::ldexp(double(Q.jlo[q]), Q.k_energy - 24) - A.w[q]) <= tol);
+        }
+        for (size_t i = 0; i < n && !bias.empty(); i++)
+            CHECK(std::fabs(std::ldexp(double(Q.hhi[i]), Q.k_energy) + std::ldexp(double(Q.hlo[i]), Q.k_energy - 24) - bias[i]) <= tol);
     }
-    if (bias_kind == 3 && sum_e > 0.0 && sum_e < 1e6) CHECK(!Q.eligible); // the enormous bias must not set the quantum
+    // one enormous bias on ordinary couplings: that site is heavy (it must not set the graph's quantum) and dominated by its bias
+    if (bias_kind == 3 && sum_e > 0.0 && sum_e < 1e6 && maxdeg <= 31) CHECK(Q.eligible && Q.heavy);
 
     // acceptance scales of arbitrary betas
     const double betas[] = {0.0, -1.0, 1e-300, 1e-12, 0.4407, 3.0, 1e12, 1e300, HUGE_VAL, r.unit() * 10.0};
