@@ -33,13 +33,16 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+# code-generation flags of the library (tests/test_build_properties.py compiles the device assembly it inspects with the same list)
+# -ffp-contract=off: the general path's f64 arithmetic must round as written (oracle parity)
+HIP_CODEGEN_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"]
+
+
 def build_lib(force=False):
-    """-ffp-contract=off: the general path's f64 arithmetic must round as written (oracle parity)."""
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(LIB, HIP_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+        _run([hipcc] + HIP_CODEGEN_FLAGS + ["-fPIC", "-shared", "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
     return LIB
 
 

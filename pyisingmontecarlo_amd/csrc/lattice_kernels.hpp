@@ -616,39 +616,6 @@ __device__ __forceinline__ void update_quad(const Mem &mem, const LatGeom &g, co
         load_signs<PMJ>(jn, g, Q, js);
         const uint32_t widx[4] = {4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3};
         quad_flips<PMJ>(own, n, widx, g, colour, t, key, vk, thr, js, jneg_uniform, Q, acc);
-#if defined(ISINGMC_DIAG_OLD_FUSED_STORE)
-        // diagnostics only (tools/store_hazard_variants.sh): the placement rounds 1-2 shipped -- store, then the counting -- with
-        // ISINGMC_DIAG_OLD_FUSED_STORE = 0: as it was; n > 0: s_nop (n - 1) behind the store; -1: immediate soffset
-        if constexpr (MEASURE) {
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE < 0)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
-                                                       vQ + mem.own_off, 0, 0);
-            else
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]}, mem.rsrc,
-                                                       vQ, mem.own_off, 0);
-            uint32_t own_new[4] = {own[0] ^ acc[0], own[1] ^ acc[1], own[2] ^ acc[2], own[3] ^ acc[3]};
-            // the asm reads and "writes" the four words: the counting below cannot be scheduled in front of it
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE == 1) asm volatile("s_nop 0" : "+v"(own_new[0]), "+v"(own_new[1]), "+v"(own_new[2]), "+v"(own_new[3]));
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE == 2) asm volatile("s_nop 1" : "+v"(own_new[0]), "+v"(own_new[1]), "+v"(own_new[2]), "+v"(own_new[3]));
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE == 4) asm volatile("s_nop 3" : "+v"(own_new[0]), "+v"(own_new[1]), "+v"(own_new[2]), "+v"(own_new[3]));
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE == 8) asm volatile("s_nop 7" : "+v"(own_new[0]), "+v"(own_new[1]), "+v"(own_new[2]), "+v"(own_new[3]));
-            // 20 + K: the third data register is complemented K wait states behind the store and restored at once (the value the
-            // counting sees is unchanged): how long is the window?
-#define ISINGMC_DIAG_WINDOW(K, NOP) \
-            if constexpr (ISINGMC_DIAG_OLD_FUSED_STORE == 20 + K) \
-                asm volatile(NOP "v_not_b32 %2, %2\n\tv_not_b32 %2, %2" : "+v"(own_new[0]), "+v"(own_new[1]), "+v"(own_new[2]), "+v"(own_new[3]));
-            ISINGMC_DIAG_WINDOW(0, "")
-            ISINGMC_DIAG_WINDOW(1, "s_nop 0\n\t")
-            ISINGMC_DIAG_WINDOW(2, "s_nop 1\n\t")
-            ISINGMC_DIAG_WINDOW(3, "s_nop 2\n\t")
-            ISINGMC_DIAG_WINDOW(4, "s_nop 3\n\t")
-            ISINGMC_DIAG_WINDOW(6, "s_nop 5\n\t")
-#undef ISINGMC_DIAG_WINDOW
-            quad_measure<PMJ>(own_new, n, js, jneg_uniform, *sat, *up);
-            pending->widx[0] = 0xFFFFFFFFu; // nothing left to store
-            return;
-        }
-#endif
         if constexpr (MEASURE) {
             // NOT stored here: the vector store (buffer_store_dwordx4 with a register offset) reads its four data registers
             // some cycles after it issues, the compiler's hazard model inserts no wait state for that form, and the counting
@@ -726,11 +693,7 @@ __global__ __launch_bounds__(256, ISINGMC_MEASURE_WAVES) void lat_sweep_measure_
     }
     // the quad's new words go out last (behind the barrier above: the compiler cannot hoist a store over it), so that nothing
     // writes the store's data registers after it has issued
-#if defined(ISINGMC_DIAG_OLD_FUSED_STORE)
-    if (gid < g.nquads && pending.widx[0] != 0xFFFFFFFFu) store_pending<VEC>(mem, pending);
-#else
     if (gid < g.nquads) store_pending<VEC>(mem, pending);
-#endif
 }
 
 template <bool VEC, bool PMJ, bool UNI>

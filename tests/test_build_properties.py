@@ -10,8 +10,13 @@ import subprocess
 
 import pytest
 
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+sys.path.insert(0, ROOT)
+from pyisingmontecarlo_amd.build import HIP_CODEGEN_FLAGS, HIP_SOURCES  # noqa: E402  (the flags the shipped library is built with)
+ASM_FLAGS = HIP_CODEGEN_FLAGS + ["-S", "--cuda-device-only"]
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +25,7 @@ def device_asm(tmp_path_factory):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("asm") / "isingmc.s"
     src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "isingmc.hip")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC] + ASM_FLAGS + ["-o", str(out), src], stderr=subprocess.DEVNULL)
     return out.read_text()
 
 
@@ -61,8 +65,7 @@ def test_packed_uniform_degree_kernels_keep_eight_waves(tmp_path):
         pytest.skip("hipcc not available")
     out = tmp_path / "pku.s"
     src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "packed_uni_kernels.hip")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC] + ASM_FLAGS + ["-o", str(out), src], stderr=subprocess.DEVNULL)
     metas = _kernel_meta(out.read_text(), "_ZN7isingmc19pk_sweep_uni_kernel")
     assert len(metas) == 32
     for name, vgpr, spill, scratch in metas:
@@ -79,8 +82,7 @@ def test_multi_class_kernels_keep_their_occupancy(tmp_path):
         pytest.skip("hipcc not available")
     out = tmp_path / "mc.s"
     src = os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", "mc_kernels.hip")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC] + ASM_FLAGS + ["-o", str(out), src], stderr=subprocess.DEVNULL)
     metas = _kernel_meta(out.read_text(), "_ZN7isingmc19lat_mc_sweep_kernel")
     assert len(metas) == 24
     for name, vgpr, spill, scratch in metas:
@@ -97,22 +99,29 @@ def test_no_vector_store_data_is_overwritten_right_behind_the_store(device_asm, 
     soffset it inserts none -- and on a loaded MI355X the fused sweep+measure kernel, whose bit counts overwrote the data
     registers in the very next instruction, stored bit counts instead of spins (round 3; wrong configurations from ~1500
     workgroups per launch on; isolated in profiles/r03_store_hazard.txt: the window is the one instruction slot behind the store).
-    No kernel of any translation unit may write such a store's data registers within 8 instructions of it."""
+    No kernel of ANY translation unit of the library (compiled with the library's own flags) may write such a store's data
+    registers within 8 instructions of it: ANY instruction whose destination overlaps them counts (vector ALU, LDS reads, memory
+    loads, accumulator moves), and a branch inside the window is followed on BOTH paths (fall-through: one slot; taken: four slots,
+    the instruction fetch is redirected); a branch to a label the scan cannot find fails the test."""
     texts = {"isingmc.hip": device_asm}
     procs = []
-    for name in ("mc_kernels.hip", "strip_kernels.hip", "spread_kernels.hip", "packed_uni_kernels.hip", "real_kernels.hip"):   # every other translation unit
+    for name in HIP_SOURCES:   # every other translation unit that may hold device code
+        if name == "isingmc.hip" or not name.endswith(".hip"):
+            continue
         out = tmp_path / (name + ".s")
-        procs.append((name, out, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                                                   "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", name)],
+        procs.append((name, out, subprocess.Popen([HIPCC] + ASM_FLAGS + ["-o", str(out), os.path.join(ROOT, "pyisingmontecarlo_amd", "csrc", name)],
                                                   stderr=subprocess.DEVNULL)))
     for name, out, proc in procs:
         assert proc.wait() == 0, name
         texts[name] = out.read_text()
     store = re.compile(r"\s(buffer_store_dwordx[34])\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
-    write = re.compile(r"(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+    dest = re.compile(r"^(\w+)\s+(?:v(\d+)\b|v\[(\d+):(\d+)\]|a(\d+)\b|a\[(\d+):(\d+)\])")   # first operand = destination
+    no_dest = ("buffer_store", "global_store", "flat_store", "ds_write", "ds_add", "ds_sub", "ds_max", "ds_min", "ds_and", "ds_or", "ds_xor",
+               "v_cmp", "v_cmpx", "buffer_atomic", "global_atomic", "s_", "exp")
     stores = 0
     for name, text in texts.items():
         lines = text.split("\n")
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\w+):", l)] if m}
         kernel = "?"
         for i, line in enumerate(lines):
             m0 = re.match(r"^(_Z\w+):", line)
@@ -123,16 +132,33 @@ def test_no_vector_store_data_is_overwritten_right_behind_the_store(device_asm, 
                 continue  # immediate soffset: the compiler inserts the wait states itself
             stores += 1
             lo, hi = int(m.group(2)), int(m.group(3))
-            seen, j = 0, i + 1
-            while j < len(lines) and seen < 8:
-                t = lines[j].strip()
-                j += 1
-                if not t or t.startswith((";", ".")):
-                    continue
-                seen += 1
-                w = write.match(t)
-                if w and not t.startswith(("v_cmp", "v_cmpx")):
-                    a = int(w.group(2) or w.group(4))
-                    b = int(w.group(3) or w.group(4))
-                    assert b < lo or a > hi, f"{name}: {kernel[:70]}: `{t}` {seen} instruction(s) behind `{line.strip()}`"
+
+            def scan(j, budget, seen_at):
+                """walk the instruction stream from line j with `budget` instruction slots left; follow branch targets too"""
+                while j < len(lines) and budget > 0:
+                    t = lines[j].strip()
+                    j += 1
+                    if not t or t.startswith((";", ".p2align", ".loc", ".cfi")) or re.match(r"^\.LBB\w+:", t):
+                        continue  # (a label: other paths may enter here -- they are scanned from their own stores)
+                    if t.startswith("s_endpgm"):
+                        return
+                    budget -= 1
+                    br = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", t)
+                    if br:
+                        key = (br.group(1), budget)
+                        assert br.group(1) in labels, f"{name}: {kernel[:70]}: branch to an unknown label behind `{line.strip()}`"
+                        if key not in seen_at:  # a TAKEN branch redirects the instruction fetch: counted as four slots of the window
+                            seen_at.add(key)
+                            scan(labels[br.group(1)] + 1, budget - 3, seen_at)
+                        if t.startswith("s_branch"):
+                            return  # unconditional: no fall-through
+                        continue
+                    d = dest.match(t)
+                    if d and not t.startswith(no_dest):
+                        a = int(d.group(2) or d.group(3) or d.group(5) or d.group(6))
+                        b = int(d.group(2) or d.group(4) or d.group(5) or d.group(7))
+                        is_acc = d.group(5) is not None or d.group(6) is not None
+                        assert is_acc or b < lo or a > hi, f"{name}: {kernel[:70]}: `{t}` {8 - budget} instruction(s) behind `{line.strip()}`"
+
+            scan(i + 1, 8, set())
     assert stores >= 4, "no register-offset vector stores found: has the pattern of this test gone stale?"

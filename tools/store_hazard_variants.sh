@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the variants are no longer in csrc/lattice_kernels.hpp: paste them back from tools/ubench/old_fused_store_variants.inc first)
 # Round 3 diagnostics: the sweep+measure kernel with the store where rounds 1-2 had it (ISINGMC_DIAG_OLD_FUSED_STORE, see
 # csrc/lattice_kernels.hpp) -- as shipped (0), with the counting pushed >= 10 instructions behind the store plus s_nop (1, 8),
 # with an immediate soffset (m1) -- against the oracle on 4096^2 x 256 (tests/diag_c2_parity2.py).  Build the variants first:

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the variants are no longer in csrc/lattice_kernels.hpp: paste them back from tools/ubench/old_fused_store_variants.inc first)
 # Round 3 diagnostics: how long after a register-soffset buffer_store_dwordx4 may its data registers not be written?  The old
 # sweep+measure kernel with the third data register complemented (and restored) K wait states behind the store
 # (ISINGMC_DIAG_OLD_FUSED_STORE = 20 + K; build: for v in 20 21 22 23 24 26; do bash tools/build_variant.sh oldfused_w$v -DISINGMC_DIAG_OLD_FUSED_STORE=$v; done)
