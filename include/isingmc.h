@@ -164,6 +164,12 @@ int isingmc_graph_create(const uint64_t *edge_a, const uint64_t *edge_b, const d
                          unsigned flags, isingmc_graph **graph_out);
 int isingmc_graph_info(const isingmc_graph *graph, isingmc_graph_info_t *info_out);
 void isingmc_graph_destroy(isingmc_graph *graph);
+/* The kernel FAMILY a container of n_experiments created now would run on: 0 checkerboard lattice kernels, 1 f64 CSR kernels
+ * (one replica per word set), 2 replica-packed bit-sliced, 3 replica-packed real-coupling.  Families 1-3 are different Markov
+ * chains for the same Hamiltonian: on a general graph the results of experiment k depend on the number of experiments of the call
+ * wherever this answer does (unless the graph was created with ISINGMC_FLAG_STABLE_PATH); isingmc_states_family: of a container. */
+int isingmc_graph_family_for(const isingmc_graph *graph, size_t n_experiments, int *family_out);
+int isingmc_states_family(const isingmc_states *states, int *family_out);
 
 /* ---- states: replaces R x { SmallRng::seed_from_u64(seed); GraphState::new(..., rng);
  * set_state(initial) } (lattice.rs:198-203) and GraphState::new_with_state_and_rng

@@ -13,6 +13,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = range(5)
 KIND_GENERAL, KIND_LATTICE2D = 0, 1
 FLAG_FORCE_GENERAL = 1
 FLAG_STABLE_PATH = 2
+FAMILIES = ("checkerboard", "csr_f64", "packed_bitsliced", "packed_real")
 
 
 class GraphInfo(C.Structure):
@@ -53,6 +54,8 @@ _PROTOTYPES = {
     "isingmc_states_set_state": (C.c_int, [_vp, C.c_size_t, _vp]),
     "isingmc_states_count": (C.c_size_t, [_vp]),
     "isingmc_states_destroy": (None, [_vp]),
+    "isingmc_graph_family_for": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int)]),
+    "isingmc_states_family": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "isingmc_states_set_option": (C.c_int, [_vp, C.c_char_p, C.c_long]),
     "isingmc_states_set_betas": (C.c_int, [_vp, _vp]),
     "isingmc_do_time_steps": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp]),
@@ -298,6 +301,12 @@ class Graph:
         self.kind = int(info.kind)
         self.state_words = int(info.state_words)
 
+    def family_for(self, n_experiments):
+        """The kernel family a container of n_experiments created now on this graph would run on (FAMILIES)."""
+        f = C.c_int()
+        _check(lib().isingmc_graph_family_for(self._h, n_experiments, C.byref(f)))
+        return FAMILIES[f.value]
+
     def close(self):
         if self._h:
             for ref in getattr(self, "_children", []):  # replica containers hold a pointer to the graph: they go first, whatever
@@ -358,6 +367,13 @@ class States:
         if st.size != self.graph.nvars:
             raise ValueError("Initial state must be of the same size as biases, or 0.")
         _check(lib().isingmc_states_set_state(self._h, replica, _p(st)))
+
+    @property
+    def family(self):
+        """'checkerboard', 'csr_f64', 'packed_bitsliced' or 'packed_real': the kernel family this container runs on."""
+        f = C.c_int()
+        _check(lib().isingmc_states_family(self._h, C.byref(f)))
+        return FAMILIES[f.value]
 
     def set_option(self, name, value):
         """One of the path / tuning switches of this container (the ISINGMC_* variable's name without the prefix)."""

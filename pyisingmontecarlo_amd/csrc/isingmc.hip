@@ -175,6 +175,28 @@ extern "C" int isingmc_states_set_state(isingmc_states *s, size_t replica, const
     return upload_state(s, replica, 1, state);
 }
 
+// kernel family: 0 checkerboard lattice kernels, 1 f64 CSR (one replica per word set), 2 replica-packed bit-sliced, 3 replica-packed real-coupling
+extern "C" int isingmc_states_family(const isingmc_states *s, int *family_out)
+{
+    if (!s || !family_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    *family_out = s->g->kind == ISINGMC_KIND_LATTICE2D ? 0 : !s->packed ? 1 : s->rj ? 3 : 2;
+    return ISINGMC_OK;
+}
+
+// ... and the family a container of n_experiments created NOW on this graph would take (the environment's switches as they are)
+extern "C" int isingmc_graph_family_for(const isingmc_graph *g, size_t n_experiments, int *family_out)
+{
+    if (!g || !family_out) return fail(ISINGMC_ERR_INVALID, "NULL argument");
+    if (g->kind == ISINGMC_KIND_LATTICE2D) { *family_out = 0; return ISINGMC_OK; }
+    isingmc_states probe;
+    probe.g = const_cast<isingmc_graph *>(g);
+    probe.opt = Options::from_env();
+    const int mode = n_experiments ? choose_packed(&probe, n_experiments) : 0;
+    probe.g = nullptr; // (the probe owns nothing: its destructor must not touch the device)
+    *family_out = mode == 0 ? 1 : mode == 1 ? 2 : 3;
+    return ISINGMC_OK;
+}
+
 extern "C" size_t isingmc_states_count(const isingmc_states *s) { return s ? s->R : 0; }
 
 extern "C" uint64_t isingmc_states_timestep(const isingmc_states *s) { return s ? s->t : 0; }

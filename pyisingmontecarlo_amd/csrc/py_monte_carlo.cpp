@@ -129,7 +129,7 @@ EdgeArrays split_edges(const py::object &edges)
 }
 
 std::shared_ptr<GraphHandle> make_graph(const EdgeArrays &E, const std::vector<double> *biases, int device,
-                                        bool force_general)
+                                        bool force_general, bool stable_path = false)
 {
     auto h = std::make_shared<GraphHandle>();
     py::gil_scoped_release nogil;
@@ -145,7 +145,7 @@ std::shared_ptr<GraphHandle> make_graph(const EdgeArrays &E, const std::vector<d
     }
     check(isingmc_graph_create(E.a.data(), E.b.data(), E.j.data(), E.a.size(), E.nvars,
                                biases ? biases->data() : nullptr, device,
-                               force_general ? ISINGMC_FLAG_FORCE_GENERAL : 0u, &h->g));
+                               (force_general ? ISINGMC_FLAG_FORCE_GENERAL : 0u) | (stable_path ? ISINGMC_FLAG_STABLE_PATH : 0u), &h->g));
     return h;
 }
 
@@ -242,11 +242,22 @@ public:
     }
     std::vector<int> get_devices() const { return devices_; }
     void set_force_general_path(bool v) { force_general_ = v; graphs_.clear(); }
-    py::dict engine_info()
+    // Experiment k of a call depends on seed k alone in the reference (lattice.rs:83-91, 198).  Here the kernel FAMILY -- and with
+    // it the Markov chain -- of a general graph normally follows the number of experiments of the call;
+    // set_stable_path(True) fixes it from the graph alone: row k of run_monte_carlo(beta, T, R) is then the same for every R > k.
+    void set_stable_path(bool v) { stable_path_ = v; graphs_.clear(); }
+    py::dict engine_info(std::optional<size_t> num_experiments)
     {
         isingmc_graph_info_t info;
         check(isingmc_graph_info(graph()->g, &info));
         py::dict d;
+        d["stable_path"] = bool(info.stable_path);
+        if (num_experiments) { // the kernel family a call with that many experiments runs on
+            int family = 0;
+            check(isingmc_graph_family_for(graph()->g, *num_experiments, &family));
+            static const char *names[] = {"checkerboard", "csr_f64", "packed_bitsliced", "packed_real"};
+            d["family"] = names[family & 3];
+        }
         d["kind"] = info.kind == ISINGMC_KIND_LATTICE2D ? "lattice2d" : "general";
         d["device"] = info.device;
         d["nvars"] = info.nvars;
@@ -258,8 +269,10 @@ public:
         d["open_x"] = bool(info.open_x);
         d["open_y"] = bool(info.open_y);
         d["packed_degree"] = info.packed_degree;
-        d["real_slots"] = info.real_slots; // 4 / 7 / 11 / 15: the real-coupling packed path applies (graphs of >= 8 000 sites: from 6 experiments on)
+        d["real_slots"] = info.real_slots; // 4 .. 31: the real-coupling packed path applies (graphs beyond the LDS-resident CSR kernel: from ONE experiment on)
         d["real_quantum_log2"] = info.real_quantum_log2;
+        d["real_energy_log2"] = info.real_energy_log2;
+        d["real_heavy_sites"] = info.real_heavy_sites;
         return d;
     }
 
@@ -376,7 +389,7 @@ private:
             const std::vector<double> *bp = nullptr;
             if (!biases_.empty()) bp = &biases_;
             else if (global_bias_ != 0.0) { b.assign(E_->nvars, global_bias_); bp = &b; } // lattice.rs:186-189
-            graphs_[slot] = make_graph(*E_, bp, devices_[slot], force_general_);
+            graphs_[slot] = make_graph(*E_, bp, devices_[slot], force_general_, stable_path_);
         }
         return graphs_[slot];
     }
@@ -452,7 +465,7 @@ private:
     std::optional<uint64_t> seed_gen_;
     bool use_allocator_ = true;
     std::vector<int> devices_;  // one block of experiments per entry (ISINGMC_DEVICES; an ordinal may repeat)
-    bool force_general_ = false;
+    bool force_general_ = false, stable_path_ = false;
     std::vector<std::shared_ptr<GraphHandle>> graphs_;
 };
 
@@ -627,7 +640,8 @@ PYBIND11_MODULE(_py_monte_carlo, m)
         .def("set_devices", &Lattice::set_devices, "devices"_a)
         .def("get_devices", &Lattice::get_devices)
         .def("set_force_general_path", &Lattice::set_force_general_path, "force"_a)
-        .def("engine_info", &Lattice::engine_info)
+        .def("set_stable_path", &Lattice::set_stable_path, "stable"_a)
+        .def("engine_info", &Lattice::engine_info, "num_experiments"_a = py::none())
         .def("run_monte_carlo", &Lattice::run_monte_carlo, "beta"_a, "timesteps"_a, "num_experiments"_a,
              "only_basic_moves"_a = py::none(), "edge_move_importance_sampling"_a = py::none(),
              "replica_range"_a = py::none())

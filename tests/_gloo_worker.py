@@ -38,6 +38,25 @@ def main():
     res.update(energies=energies.tolist(), perm=pt.get_permutation().tolist(), swaps=pt.get_total_swaps(),
                states_sum=int(states.sum()), rungs=rungs.tolist(), lo=lo, hi=hi,
                local_states=states.astype(np.uint8).reshape(states.shape[0], -1).sum(axis=1).tolist())
+    # 3. ADVICE r03: ranks that disagree on on-stream tempering (here: only rank 0's shard could attach the ladder) must ALL take
+    #    the host swap step, and nobody may have attached anything before that was agreed (pt_can_attach has no side effects)
+    class HalfEligibleEngine(OracleLatEngine):
+        supports_on_stream_pt = True
+
+        def make_states(self, seeds, replica_range=None):
+            st = super().make_states(seeds, replica_range)
+            st.attached = False
+            st.pt_can_attach = lambda *a: rank == 0
+            st.pt_attach = lambda *a: setattr(st, "attached", True)
+            return st
+
+    pt2 = ClassicalTempering(edges, seed=77, engine_factory=lambda: HalfEligibleEngine(W, H))
+    for b in np.linspace(0.40, 0.46, 5):
+        pt2.add_graph(b)
+    pt2.timesteps(3)
+    states2, energies2, _ = pt2.timesteps_sample(12, replica_swap_freq=2, sampling_freq=4)
+    res.update(mixed_on_stream=bool(pt2._on_stream), mixed_attached=bool(pt2._states.attached), mixed_energies=energies2.tolist(),
+               mixed_perm=pt2.get_permutation().tolist())
     with open(out_path, "w") as f:
         json.dump(res, f)
     dist.destroy_process_group()

@@ -46,6 +46,10 @@ def test_sharded_ladder_equals_single_process(tmp_path, exact):
         np.testing.assert_array_equal(r["energies"], energies)           # identical on every rank
         assert r["perm"] == pt.get_permutation().tolist()
         assert r["swaps"] == pt.get_total_swaps()
+        # one rank could attach the on-stream ladder, the other not: both on the host swap step, nothing attached, same results
+        assert r["mixed_on_stream"] is False and r["mixed_attached"] is False
+        np.testing.assert_array_equal(r["mixed_energies"], energies)
+        assert r["mixed_perm"] == pt.get_permutation().tolist()
     assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 3, 3, 5)
     # configurations stay on their rank; indexed by rung they equal the single-process arrays
     total = sum(r["states_sum"] for r in res)

@@ -208,6 +208,8 @@ def test_stable_path_makes_experiments_prefix_stable(capi, exact):
         assert g.info.stable_path == int(stable)
         for R in (1, 2, 512):
             st = capi.States(g, seeds[:R])
+            # the family is visible per call: which chain will these experiments run?
+            assert st.family == g.family_for(R) == ("packed_real" if stable or R == 512 else "csr_f64")
             st.do_time_steps(T, beta)
             res[stable, R] = (st.states(), st.energies())
     for R in (1, 2):
@@ -224,6 +226,16 @@ def test_stable_path_makes_experiments_prefix_stable(capi, exact):
     one.do_time_steps(T, beta)
     many.do_time_steps(T, beta)
     assert np.array_equal(one.states()[0], many.states()[0]) and one.energies()[0] == many.energies()[0]
+    # ... and through the reference's Python surface: Lattice.set_stable_path / engine_info(num_experiments)
+    import py_monte_carlo
+    lat = py_monte_carlo.Lattice.from_arrays(ea, eb, ej, seed_gen=5)
+    assert lat.engine_info(1)["family"] == "csr_f64" and lat.engine_info(512)["family"] == "packed_real"
+    lat.set_stable_path(True)
+    info = lat.engine_info(1)
+    assert info["family"] == "packed_real" and info["stable_path"] is True
+    e1, s1 = lat.run_monte_carlo(beta, T, 1)
+    e9, s9 = lat.run_monte_carlo(beta, T, 512)
+    assert e1[0] == e9[0] and np.array_equal(s1[0], s9[0])
     # uniform-|J| graphs (bit-sliced packed family): the same guarantee with the flag
     ea3, eb3, ej3 = exact.square_lattice_edges(96, 64, -1.0)
     g3 = capi.Graph(ea3, eb3, ej3, force_general=True, stable_path=True)
