@@ -87,6 +87,38 @@ def cpu_baseline(ea, eb, ej, nvars):
                       f"{sec:.1f} s; C restatement of the reference algorithm, not the Rust crate"}
 
 
+def library_sha256():
+    """sha256 of the libisingmc.so this process loads (profiles/*.json carry the hash of the binary they were measured on)."""
+    import hashlib
+    from pyisingmontecarlo_amd import _capi
+    with open(_capi.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def source_sha256():
+    """sha256 over the library's sources and code-generation flags: a rebuild of the same code need not give the same bytes
+    (it does in this image), the same code it is."""
+    import hashlib
+    from pyisingmontecarlo_amd.build import CSRC, HIP_CODEGEN_FLAGS
+    h = hashlib.sha256(" ".join(HIP_CODEGEN_FLAGS).encode())
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".hpp", ".inc", ".cpp")) and name != "py_monte_carlo.cpp":
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def profile_matches(d):
+    """Do the committed counters belong to the code that is running?  Same binary, or the same sources rebuilt."""
+    if not d:
+        return False, None
+    if d.get("library_sha256") == library_sha256():
+        return True, "same binary"
+    if d.get("source_sha256") == source_sha256():
+        return True, "same sources, rebuilt"
+    return False, "counters of another build"
+
+
 def _profile_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -99,7 +131,10 @@ def traffic_from_profile():
     """HBM bytes per colour half-sweep (all replicas) from the committed rocprofv3 --pmc passes, or None.
     NOT measured in this run: counters need their own rocprofv3 passes (tools/profile.sh)."""
     d = _profile_json("traffic_latest.json")
-    return d.get("hbm_bytes_per_launch") if d else None
+    ok, why = profile_matches(d)
+    return (d.get("hbm_bytes_per_launch") if ok else None), {"profile_binary_sha": d.get("library_sha256") if d else None,
+                                                             "profile_source_sha": d.get("source_sha256") if d else None, "profile_match": why,
+                                                             "profile_measured": d.get("measured") if d else None}
 
 
 def copy_ceiling_gbs(torch, mib=2048, reps=10):
@@ -130,7 +165,7 @@ def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
     The two terms come from different sessions: the ratio is reported as an estimate and clamped to 1 (a kernel cannot be
     busier than the cycles it owns; raw_ratio keeps what the division gave, saturated says it was clamped)."""
     d = _profile_json("sq_latest.json")
-    if not d or not clock_ghz:
+    if not d or not clock_ghz or not profile_matches(d)[0]:  # counters of another build say nothing about this one: refused
         return None
     owned = avg_launch_us * 1e-6 * clock_ghz * 1e9 * N_CU * SIMD_PER_CU / quads_per_launch
     busy = d["valu_busy_cycles_per_quad"]
@@ -138,7 +173,8 @@ def valu_bound(avg_launch_us, clock_ghz, quads_per_launch):
     return {"bound": "valu", "achieved": busy, "peak": owned, "unit": "SIMD cycles per wave of 64 quads (8192 spins)",
             "frac": min(1.0, raw), "raw_ratio": raw, "saturated": raw >= 1.0, "kind": "profile-derived estimate",
             "clock_ghz": clock_ghz, "valu_insts_per_quad": d.get("valu_insts_per_quad"),
-            "achieved_source": d.get("source"), "peak_source": "this run: HIP-event launch time x live shader clock"}
+            "achieved_source": d.get("source"), "profile_binary_sha": d.get("library_sha256"), "profile_match": profile_matches(d)[1],
+            "peak_source": "this run: HIP-event launch time x live shader clock"}
 
 
 def main():
@@ -217,9 +253,12 @@ def main():
         bytes_per_launch = BYTES_PER_ATTEMPT * R * nvars / 2
         avg_launch_us = device_ms * 1e3 / launches
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
+        traffic, traffic_meta = traffic_from_profile()
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(),
-                    "traffic_source": "profiles/traffic_latest.json (committed rocprofv3 --pmc passes, not measured in this run)",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/traffic_latest.json (committed rocprofv3 --pmc passes, not measured in this run; null when they "
+                                      "belong to another build)",
+                    **traffic_meta,
                     "kernel": "lat_sweep_loop_kernel<uniformJ> (2 quads per thread; replicas in 2 stream lanes)",
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_launch_us,
@@ -248,6 +287,7 @@ def main():
             "shader_clock_ghz": clock_ghz,
             "energy_per_site": e_site,
             "ingest_s": t_ingest,
+            "library_sha256": library_sha256(), "source_sha256": source_sha256(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ea, eb, ej, nvars)

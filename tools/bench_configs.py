@@ -18,12 +18,14 @@ from pyisingmontecarlo_amd.tempering import ClassicalTempering  # noqa: E402
 
 
 def _pmc(name):
-    """HBM bytes per sweep launch from the committed counter passes (profiles/traffic_<name>.json), or None."""
+    """HBM bytes per sweep launch from the committed counter passes (profiles/traffic_<name>.json) -- of THIS build, or None."""
     try:
         with open(os.path.join(ROOT, "profiles", f"traffic_{name}.json")) as f:
-            return json.load(f)
+            d = json.load(f)
     except (OSError, ValueError):
         return None
+    from bench import profile_matches
+    return d if profile_matches(d)[0] else None
 
 
 def square(W, H, rng=None):
@@ -62,6 +64,7 @@ def c4(steps):
     if pmc:
         out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L * L / 2)
         out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
+        out["counters"] = f"profiles/traffic_c4.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
     return out
 
 
@@ -77,9 +80,15 @@ def c3(steps):
     n_blocks = steps // 10
     pt.timesteps(n_blocks * 10, replica_swap_freq=10)   # sweeps + exchange rounds, all on the engine's stream
     dt = time.perf_counter() - t0
-    return {"config": "c3", "lattice": [L, L], "rungs": G, "steps": n_blocks * 10, "swap_every": 10,
-            "attempts_per_s": G * L * L * n_blocks * 10 / dt, "ms_per_step": dt * 1e3 / (n_blocks * 10),
-            "hbm_frac": G * L * L * n_blocks * 10 / dt * 0.375 / 8e12, "total_swaps": pt.get_total_swaps()}
+    out = {"config": "c3", "lattice": [L, L], "rungs": G, "steps": n_blocks * 10, "swap_every": 10,
+           "attempts_per_s": G * L * L * n_blocks * 10 / dt, "ms_per_step": dt * 1e3 / (n_blocks * 10),
+           "hbm_frac": G * L * L * n_blocks * 10 / dt * 0.375 / 8e12, "total_swaps": pt.get_total_swaps()}
+    pmc = _pmc("c3")  # one strip launch = 10 timesteps of all 64 rungs
+    if pmc:
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (G * L * L * 10)
+        out["hbm_frac_counters"] = out["attempts_per_s"] * out["pmc_bytes_per_attempt"] / 8e12
+        out["counters"] = f"profiles/traffic_c3.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
+    return out
 
 
 def c5(steps):
@@ -106,6 +115,7 @@ def c5(steps):
     if pmc:
         out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L ** 3 / 2)
         out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
+        out["counters"] = f"profiles/traffic_c5.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
     return out
 
 
