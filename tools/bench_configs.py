@@ -62,7 +62,7 @@ def c4(steps):
                    "stay in L2, so the HBM traffic is near 0.375 B/attempt: see hbm_frac_counters"}
     pmc = _pmc("c4")                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script (profiles/)
     if pmc:
-        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L * L / 2)
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_attempt"]
         out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
         out["counters"] = f"profiles/traffic_c4.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
     return out
@@ -85,7 +85,7 @@ def c3(steps):
            "hbm_frac": G * L * L * n_blocks * 10 / dt * 0.375 / 8e12, "total_swaps": pt.get_total_swaps()}
     pmc = _pmc("c3")  # one strip launch = 10 timesteps of all 64 rungs
     if pmc:
-        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (G * L * L * 10)
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_attempt"]   # (the planes of a strip stay in LDS for all timesteps of a launch)
         out["hbm_frac_counters"] = out["attempts_per_s"] * out["pmc_bytes_per_attempt"] / 8e12
         out["counters"] = f"profiles/traffic_c3.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
     return out
@@ -113,7 +113,7 @@ def c5(steps):
                    "path avoids (32 replicas share every index): vs_per_replica_csr_ceiling is the speed-up over THAT roofline"}
     pmc = _pmc("c5")
     if pmc:
-        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_launch"] / (R * L ** 3 / 2)
+        out["pmc_bytes_per_attempt"] = pmc["hbm_bytes_per_attempt"]
         out["hbm_frac_counters"] = rate * out["pmc_bytes_per_attempt"] / 8e12
         out["counters"] = f"profiles/traffic_c5.json ({pmc.get('measured')}, library {str(pmc.get('library_sha256'))[:12]})"
     return out

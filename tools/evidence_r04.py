@@ -71,21 +71,29 @@ if sq:
         "valu_insts_per_quad": sq["SQ_INSTS_VALU"] / (2 * waves), "salu_insts_per_quad": sq["SQ_INSTS_SALU"] / (2 * waves),
         "valu_busy_cycles_per_quad": sq["SQ_THREAD_CYCLES_VALU"] * 4 / 64 / (2 * waves), "raw": sq})
 
-# ---- c3 / c4 / c5 / real path: tools/pmc_traffic.sh tables
-for tag, needle, note in (("c3", "lat_strip_kernel", "raw FETCH_SIZE x 2 (16-byte streaming loads of the strips' rows)"),
-                          ("c4", "lat_sweep_loop_kernel<true>", "16-byte loads => read = 2 x FETCH_SIZE x 1024"),
-                          ("c5", "pk_sweep_uni_kernel", "4-byte loads per lane: the x2 FETCH_SIZE correction of the guide is calibrated for 16-byte streaming loads, so the "
-                                                        "RAW figure is used for reads (half of the script's printed read column)"),
-                          ("real", "rj_sweep_kernel", "4-byte loads per lane: RAW FETCH_SIZE for reads")):
+# ---- c3 / c4 / c5 / real path: tools/pmc_traffic.sh tables.  Reads = 2 x FETCH_SIZE x 1024 for EVERY kernel here: the guide's
+# correction is stated for 16-byte-per-lane streaming loads, and tools/ubench/fetch_calib.hip (round 4, profiles/r04_fetch_calibration.txt)
+# measures exactly the same factor for the packed kernels' 4-byte-per-lane loads (FETCH_SIZE x 1024 = 0.50001 of 1 GiB read once, both
+# widths).  Rounds 2-3 took the RAW figure for those kernels and under-reported their read traffic by 2.
+# (tag, kernel-name needle, timesteps the matched dispatches cover in the script's command, attempts per timestep)
+RUNS = (("c3", "lat_strip_kernel<false, 4, true>", 240, 64 * 1024 * 1024, "bench_configs.py c3 --steps 200: the 40- and the 200-timestep ladder calls (exchange rounds in the launch)"),
+        ("c4", "lat_sweep_loop_kernel<true>", 30, 128 * 2048 * 2048, "bench_configs.py c4 --steps 20: 10 + 20 timesteps x 2 colours, one dispatch of 128 replicas each"),
+        ("c5", "pk_sweep_uni_kernel", 12, 64 * 256 ** 3, "bench_configs.py c5 --steps 10: 2 + 10 timesteps x 2 classes (x 2 group lanes in the timed call)"),
+        ("real", "rj_sweep_kernel", 65, 128 * 2048 * 2048, "real_bench.py 20 '2048^2 gaussian x128': 3 + 2 x 20 + 2 + 20 timesteps x 2 classes (x 2 group lanes in the timed calls)"))
+for tag, needle, timesteps, per_step, what in RUNS:
     rows = traffic_rows(os.path.join(out, f"traffic_{tag}.txt"))
     hit = [(k, v) for k, v in rows.items() if needle in k]
     if not hit:
         print("no rows for", tag, list(rows)[:5])
         continue
     k, v = max(hit, key=lambda kv: kv[1]["launches"])
-    read = v["read_mb_x2"] * 1e6 * (0.5 if tag in ("c5", "real") else 1.0)
-    dump(f"traffic_{tag}.json", {"source": f"tools/evidence_r04.sh: tools/pmc_traffic.sh r04_{tag} ({note})", "kernel": k, "launches": v["launches"], "avg_us": v["us"],
-                                 "read_bytes": read, "write_bytes": v["write_mb"] * 1e6, "hbm_bytes_per_launch": read + v["write_mb"] * 1e6})
-    s = load(os.path.join(out, f"sq_{tag}.json"))
-    if s:
-        dump(f"r04_sq_{tag}.json", {"source": f"tools/evidence_r04.sh: tools/pmc_sq.sh r04_{tag}, per-dispatch means", "kernel_filter": needle, "counters": s})
+    read, write = v["read_mb_x2"] * 1e6, v["write_mb"] * 1e6
+    total = v["launches"] * (read + write)
+    dump(f"traffic_{tag}.json", {"source": f"tools/evidence_r04.sh: tools/pmc_traffic.sh r04_{tag} ({what}); read = 2 x FETCH_SIZE x 1024 (calibrated: "
+                                           "profiles/r04_fetch_calibration.txt), write = WRITE_SIZE x 1024",
+                                 "kernel": k, "dispatches": v["launches"], "avg_us": v["us"], "read_bytes_per_dispatch": read, "write_bytes_per_dispatch": write,
+                                 "timesteps_covered": timesteps, "attempts_covered": timesteps * per_step, "hbm_bytes_total": total,
+                                 "hbm_bytes_per_attempt": total / (timesteps * per_step)})
+    sq_ = load(os.path.join(out, f"sq_{tag}.json"))
+    if sq_:
+        dump(f"r04_sq_{tag}.json", {"source": f"tools/evidence_r04.sh: tools/pmc_sq.sh r04_{tag}, per-dispatch means", "kernel_filter": needle, "counters": sq_})
