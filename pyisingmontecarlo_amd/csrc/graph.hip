@@ -466,11 +466,12 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
                             if (e[l] == PK_NO_NBR || off(l) != delta) { odd_lanes++; odd_lane = l; }
                             mask |= uint64_t(e[l] != PK_NO_NBR && (e[l] >> 31)) << l;
                         }
-                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, delta);
+                        // (the one-degree kernels' headers carry the translation in BYTES: 4 x delta fits, the state of a group is below 2^31 bytes)
+                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, 4u * delta);
                         else if (odd_lanes == 1 && e[odd_lane] != PK_NO_NBR) { // a translation but for one lane (a row's wrap-around)
                             const int32_t ex = int32_t(off(odd_lane) - delta);
                             if (ex >= -(1 << 23) && ex < (1 << 23))
-                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), delta);
+                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), 4u * delta);
                         }
                         sign[B * PK_MAX_DEG + i] = make_uint2(uint32_t(mask), uint32_t(mask >> 32));
                     }

@@ -36,9 +36,9 @@ struct PkGraphDev {
 };
 
 // Block headers of the one-degree kernels (packed_uni_kernels.hpp), [n_pos / 64][PK_MAX_DEG] each:
-//   shift[B][i] = {PK_HDR_UNIFORM, d} when slot i of the 64 positions of block B is one translation p -> p + d
-//                 (whatever the signs);
-//                 {PK_HDR_UNIFORM_BUT_ONE | lane << 2 | (e & 0xFFFFFF) << 8, d} when it is that translation for every lane but
+//   shift[B][i] = {PK_HDR_UNIFORM, 4 d} when slot i of the 64 positions of block B is one translation p -> p + d
+//                 (whatever the signs; the shift in BYTES: the table-free instantiation adds it to a byte offset directly);
+//                 {PK_HDR_UNIFORM_BUT_ONE | lane << 2 | (e & 0xFFFFFF) << 8, 4 d} when it is that translation for every lane but
 //                 one, whose neighbour is p + d + e (-2^23 <= e < 2^23): where a row of a periodic lattice wraps around inside
 //                 the block -- on BASELINE c5's 256^3 lattice two of the 24 (block, slot) pairs of EVERY wave, which each cost a
 //                 dependent table read before the gathers could be issued (round 4: +8 %);

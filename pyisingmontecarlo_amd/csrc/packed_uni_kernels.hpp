@@ -109,6 +109,8 @@ template <int D, bool TABLE>
 __device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0,
                                             const uint32_t lane, uint32_t (&ent)[4][PK_MAX_DEG])
 {
+    // ent: BYTE offsets of the neighbour words when TABLE is false (the headers carry their shifts in bytes: no shift per gather),
+    // positions (possibly with a table entry's sign bit) when it is true
     uint2 h[4][PK_MAX_DEG];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -119,7 +121,11 @@ __device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsr
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int i = 0; i < D; i++) ent[q][i] = p0 + 64 * q + uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y));
+        for (int i = 0; i < D; i++) {
+            const uint32_t hy = uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)); // 4 x the translation
+            if constexpr (TABLE) ent[q][i] = p0 + 64 * q + uint32_t(int32_t(hy) >> 2);
+            else ent[q][i] = 4 * (p0 + 64 * q) + hy;
+        }
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -127,7 +133,9 @@ __device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsr
             const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
             if (hx != PK_HDR_UNIFORM) {
                 asm volatile(""); // (a real scalar branch, skipped by nearly every slot: if-converted, each slot pays ten instructions)
-                if (!TABLE || (hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? uint32_t(int32_t(hx) >> 8) : 0u;
+                const uint32_t e = uint32_t(int32_t(hx) >> 8);
+                if (!TABLE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
+                else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e : 0u;
                 else ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
             }
         }
@@ -135,7 +143,7 @@ __device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsr
 
 // memory phase of the position-quad led by p0: neighbour positions, the gathers (the shift to a byte offset drops the sign bit of a
 // table entry), and the own words LAST -- the wait the compiler puts in front of the first gather (a table entry may be pending)
-// then finds nothing of ours in flight.
+// then finds nothing of ours in flight.  TABLE = false: own words first, byte offsets straight from the headers.
 template <int D, bool TABLE>
 __device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H,
                                          const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
@@ -150,7 +158,7 @@ __device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, c
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, ent[q][i] << 2, 0, 0);
+        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, TABLE ? ent[q][i] << 2 : ent[q][i], 0, 0);
     if constexpr (TABLE) {
 #pragma unroll
         for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);

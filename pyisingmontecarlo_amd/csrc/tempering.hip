@@ -432,6 +432,7 @@ extern "C" int isingmc_pt_group_allgather(isingmc_pt_group *grp)
         if (rc != 0) return rccl_fail(rc, "ncclGroupStart");
         for (size_t k = 0; k < n && rc == 0; k++) {
             isingmc_states *s = grp->shards[k];
+            (void)hipSetDevice(s->g->device); // (the stream belongs to this communicator's device)
             rc = rccl().AllGather(s->d_pt_local, s->d_pt_all, grp->per, RCCL_FLOAT64, grp->comms[k], s->stream);
         }
         const int rc2 = rccl().GroupEnd();

@@ -76,7 +76,25 @@ def main():
     g = _capi.Graph(ea, eb, ej, force_general=True)
     ok &= soak("2048^2 Gaussian glass (real-coupling packed)", g, 128, 1500, 250, 0.8)
     ok &= soak("2048^2 Gaussian glass, energies after every step", g, 128, 300, 100, 0.8, per_step=True)
+    ok &= soak("2048^2 Gaussian glass x 4 (partly used replica group)", g, 4, 300, 100, 0.8)
+    os.environ["ISINGMC_DISABLE_REAL"] = "1"   # (read when the containers are created)
     ok &= soak("2048^2 Gaussian glass x 4 (f64 CSR path)", g, 4, 300, 100, 0.8)
+    del os.environ["ISINGMC_DISABLE_REAL"]
+    # round 4: a site pinned by a bias six orders above the couplings (heavy site: its own quantum), and a graph of degree <= 31
+    ea, eb, ej = square(4096, 4096)
+    h = np.zeros(4096 * 4096)
+    h[7] = 1e6
+    g = _capi.Graph(ea, eb, ej, biases=h)
+    assert g.info.real_heavy_sites == 1
+    ok &= soak("4096^2 ferromagnet, one pinned spin (heavy site)", g, 64, 600, 100, 0.4407)
+    n = 1 << 18
+    a_ = rng.integers(0, n, 3 * n).astype(np.uint64)
+    b_ = (a_ + rng.integers(1, n, 3 * n).astype(np.uint64)) % np.uint64(n)
+    deg = np.bincount(np.concatenate([a_, b_]).astype(np.int64), minlength=n)
+    keep = (deg[a_.astype(np.int64)] <= 31) & (deg[b_.astype(np.int64)] <= 31)
+    g = _capi.Graph(a_[keep], b_[keep], rng.normal(size=int(keep.sum())) * 0.3, nvars=n, biases=rng.normal(size=n) * 0.2)
+    assert g.info.real_slots in (23, 31), g.info.real_slots
+    ok &= soak(f"random graph, degree <= 31 ({g.info.real_slots} ELL slots)", g, 64, 600, 100, 0.7)
     print("SOAK", "OK" if ok else "FAILED")
     return 0 if ok else 1
 
