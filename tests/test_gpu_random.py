@@ -78,13 +78,14 @@ def test_random_packed_graphs(capi, oracle, monkeypatch, g, R, T, beta, per_repl
 
 @st.composite
 def random_real_graph(draw):
-    """any couplings / biases, degree <= 15: what the real-coupling packed path takes (duplicate bonds and self-loops included)"""
+    """any couplings / biases, degree <= 31: what the real-coupling packed path takes (duplicate bonds and self-loops included);
+    round 4: also sites pinned by a bias orders of magnitude above the couplings and one enormous bond (heavy sites)"""
     n = draw(st.integers(2, 90))
-    m = draw(st.integers(1, 3 * n))
+    m = draw(st.integers(1, 8 * n))
     rng = np.random.default_rng(draw(st.integers(0, 2 ** 32 - 1)))
     ea = rng.integers(0, n, m).astype(np.uint64)
     eb = rng.integers(0, n, m).astype(np.uint64)
-    maxdeg = draw(st.sampled_from([3, 4, 7, 10, 15]))
+    maxdeg = draw(st.sampled_from([3, 4, 7, 10, 15, 22, 31]))
     keep, deg = [], np.zeros(n, dtype=int)
     for k in range(m):
         a, b = int(ea[k]), int(eb[k])
@@ -102,6 +103,16 @@ def random_real_graph(draw):
     nvars = int(max(ea.max(), eb.max())) + 1 + draw(st.integers(0, 3))
     scale = float(np.abs(ej).mean())
     biases = {0: None, 1: rng.normal(size=nvars) * scale, 2: np.full(nvars, 0.7 * scale)}[draw(st.integers(0, 2))]
+    heavy = draw(st.sampled_from(["none", "none", "bias", "two_biases", "bond"]))
+    if heavy in ("bias", "two_biases"):
+        biases = np.zeros(nvars) if biases is None else biases.copy()
+        biases[int(rng.integers(0, nvars))] = float(rng.choice([-1.0, 1.0])) * scale * 10.0 ** float(rng.integers(3, 8))
+        if heavy == "two_biases":
+            biases[int(rng.integers(0, nvars))] = float(rng.choice([-1.0, 1.0])) * scale * 10.0 ** float(rng.integers(2, 5))
+    elif heavy == "bond":
+        k = int(np.flatnonzero(ea != eb)[0])
+        ej = ej.copy()
+        ej[k] = scale * 3e5
     return ea, eb, ej, nvars, biases
 
 
@@ -116,13 +127,13 @@ def test_random_real_coupling_graphs(capi, oracle, g, R, T, beta, per_replica, p
         return
     os.environ["ISINGMC_FORCE_REAL"] = "1"
     try:
-        scale = float(np.abs(ej).mean())
+        scale = float(np.median(np.abs(ej)))   # (the typical coupling: a heavy bond must not set the temperatures)
         seeds = capi.make_seeds(seed, R)
         graph = capi.Graph(ea, eb, ej, nvars=nvars, biases=biases)
         if graph.info.real_slots == 0:   # one |J| and no biases: the bit-sliced packed path keeps such a graph
             assert biases is None and len(set(np.abs(ej[ea != eb]))) == 1
             return
-        assert graph.info.real_slots in (4, 7, 11, 15)
+        assert graph.info.real_slots in (4, 7, 11, 15, 23, 31)
         states = capi.States(graph, seeds)
         if per_replica:
             betas = np.linspace(0.0, 2.0, R) / scale
