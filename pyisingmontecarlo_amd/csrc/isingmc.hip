@@ -512,7 +512,8 @@ static void rj_launch_timestep(isingmc_states *s, const RjBeta *betas, uint32_t 
     }
 }
 
-static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride, size_t gb, size_t ge, hipStream_t stream)
+static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t tab_stride, const uint32_t *philox_tab, size_t gb, size_t ge,
+                               hipStream_t stream)
 {
     const isingmc_graph *g = s->g;
     const bool no_uni = s->opt.disable_packed_uniform != 0; // A/B switch: results are the same either way
@@ -527,7 +528,8 @@ static void pk_launch_timestep(isingmc_states *s, const uint32_t *tabs, uint32_t
             if (mid > b)
                 (void)pk_uni_launch_sweep(g->pk_uni_deg, tab_stride == 0, g->pk_uni_pmj, uint32_t(ng), stream,
                                           s->d_state + g0 * g->pk.n_pos, g->pk, g->pk_uni, b, mid, s->t, s->d_keys + g0,
-                                          tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride, g->pk_class_table[c] != 0);
+                                          tabs + (tab_stride ? g0 * tab_stride : 0), tab_stride,
+                                          philox_tab + g0 * pk_uni_philox_table_words(), g->pk_class_table[c] != 0);
             if (e > mid)
                 hipLaunchKernelGGL(pk_sweep_kernel, dim3((e - mid) / 1024 + ((e - mid) % 1024 != 0), unsigned(ng)), dim3(256), 0, stream,
                                    s->d_state + g0 * g->pk.n_pos, g->pk, mid, e, s->t, s->d_keys + g0,
@@ -590,6 +592,10 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
         h_step_counts.resize(chunk * CS * 2);
     }
     std::vector<uint32_t> h_tabs;
+    // one-degree kernels: the wave-uniform halves of every timestep's Philox calls, written by one small launch per chunk
+    uint32_t *d_philox = nullptr;
+    const size_t philox_words = !s->rj && g->pk_uni_deg && !s->opt.disable_packed_uniform ? s->groups * pk_uni_philox_table_words() : 0;
+    if (philox_words) TRY(scratch.alloc(&d_philox, chunk * philox_words));
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     // The replica groups are independent: mid-size launches (a few waves per SIMD: the 64^3 glass x 64 replicas puts ONE wave on a
@@ -613,8 +619,7 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
         isingmc_states *s;
         ~LaneJoin() { if (s->n_lanes > 1) (void)lanes_join(s); }
     } lane_join{s};
-    if (want_lanes > 1) TRY(lanes_fork(s, want_lanes));
-    const size_t n_lanes = s->n_lanes, per_lane = (s->groups + n_lanes - 1) / n_lanes;
+    const size_t n_lanes = want_lanes, per_lane = (s->groups + n_lanes - 1) / n_lanes;
     const auto launch_step = [&](size_t k) {
         for (size_t lane = 0; lane < n_lanes; lane++) {
             const size_t gb = lane * per_lane, ge = std::min(s->groups, gb + per_lane);
@@ -623,12 +628,17 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             if (s->rj) {
                 if (s->has_betas) rj_launch_timestep(s, s->d_rj_betas, 32, gb, ge, st);
                 else rj_launch_timestep(s, d_rj_steps + (beta_stride ? k : 0), 0, gb, ge, st);
-            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS, gb, ge, st);
-            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0, gb, ge, st);
+            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS, d_philox + k * philox_words, gb, ge, st);
+            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0, d_philox + k * philox_words, gb, ge, st);
         }
     };
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
+        const bool new_step_tabs = !s->has_betas && (beta_stride || k0 == 0);
+        if (k0 > 0 && (new_step_tabs || philox_words)) { // the chunk's tables are overwritten: every lane must have finished reading them
+            if (s->n_lanes > 1) TRY(lanes_join(s));
+            if (new_step_tabs) HIP_TRY(hipStreamSynchronize(s->stream)); // (written from the host)
+        }
         if (!s->has_betas && s->rj && (beta_stride || k0 == 0)) {
             h_rj.resize(beta_stride ? nk : 1);
             for (size_t k = 0; k < h_rj.size(); k++) rj_beta(betas[(k0 + k) * beta_stride], g->rj_k, &h_rj[k].shift, &h_rj[k].mant);
@@ -641,6 +651,8 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             }
             HIP_TRY(hipMemcpy(d_step_tabs, h_tabs.data(), h_tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
+        if (philox_words) HIP_TRY(pk_uni_launch_philox_table(s->stream, d_philox, s->d_keys, uint32_t(s->groups), s->t, uint32_t(nk)));
+        if (want_lanes > 1 && s->n_lanes <= 1) TRY(lanes_fork(s, want_lanes)); // (behind the table launch: the lanes wait for it)
         for (size_t k = 0; k < nk && rc == ISINGMC_OK; k++) {
             launch_step(k);
             s->t++;
@@ -653,10 +665,6 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
                 for (size_t r = 0; r < R; r++)
                     energies_per_step[r * timesteps + k0 + k] = pk_energy(g, s->rj, h_step_counts[(k * CS + r + s->pk_bit0) * 2],
                                                                           h_step_counts[(k * CS + r + s->pk_bit0) * 2 + 1]);
-        } else if (k0 + nk < timesteps && !s->has_betas && beta_stride) {
-            // the next chunk overwrites the step tables: every lane must have finished reading them
-            if (s->n_lanes > 1) { TRY(lanes_join(s)); HIP_TRY(hipStreamSynchronize(s->stream)); TRY(lanes_fork(s, want_lanes)); }
-            else HIP_TRY(hipStreamSynchronize(s->stream));
         }
     }
     if (s->n_lanes > 1) { const int jrc = lanes_join(s); if (rc == ISINGMC_OK) rc = jrc; }

@@ -44,9 +44,13 @@ struct PkGraphDev {
 //                 dependent table read before the gathers could be issued (round 4: +8 %);
 //                 else {PK_HDR_MIXED, 0}: addresses from nbr_ell;
 //   sign[B][i]  = bit l set <=> the slot-i bond of position 64 B + l has J > 0 (only read when the signs differ)
+//   quad_flags[Q] bit q set <=> some slot of block 4 Q + q is NOT {PK_HDR_UNIFORM, ...} (the block takes the per-slot code)
+// The shifts are stored BIASED by 4 n_pos bytes (never negative): the kernels use them as the scalar offset of a buffer load,
+// which is unsigned, against a base moved down by the same amount.
 struct PkUniHeaders {
     const uint2 *shift;
     const uint2 *sign;
+    const uint32_t *quad_flags; // [n_pos / 256]
     uint32_t negmask; // one sign for every bond: 0 (J > 0) or ~0 (J < 0)
 };
 
@@ -56,8 +60,13 @@ struct PkUniHeaders {
 // n_groups: grid.y (the launch covers positions [class_begin, class_end) of that many replica groups)
 hipError_t pk_uni_launch_sweep(int degree, bool uniform_beta, bool mixed_signs, uint32_t n_groups, hipStream_t stream, uint32_t *state,
                                const PkGraphDev &G, const PkUniHeaders &H, uint32_t class_begin, uint32_t class_end, uint64_t t,
-                               const uint2 *group_keys, const uint32_t *tabs, uint32_t tab_stride, bool needs_table = true);
+                               const uint2 *group_keys, const uint32_t *tabs, uint32_t tab_stride, const uint32_t *philox_tab,
+                               bool needs_table = true);
 // needs_table = false: no (block, slot) header of [class_begin, class_end) is PK_HDR_MIXED (the host has checked): the instantiation
 // without table reads
+// philox_tab: the wave-uniform halves of timestep t's Philox calls for the launch's groups, pk_uni_philox_table_words() words per group,
+// written by pk_uni_launch_philox_table for timesteps t0 .. t0 + n_steps - 1 as out[(k n_groups + g) words + ...] from the groups' keys
+uint32_t pk_uni_philox_table_words();
+hipError_t pk_uni_launch_philox_table(hipStream_t stream, uint32_t *out, const uint2 *group_keys, uint32_t n_groups, uint64_t t0, uint32_t n_steps);
 
 } // namespace isingmc

@@ -8,10 +8,10 @@ namespace isingmc {
 template <int D>
 static void launch_degree(bool uniform_beta, bool mixed_signs, dim3 grid, hipStream_t stream, uint32_t *state, const PkGraphDev &G,
                           const PkUniHeaders &H, uint32_t class_begin, uint32_t class_end, uint64_t t, const uint2 *group_keys,
-                          const uint32_t *tabs, uint32_t tab_stride, bool table)
+                          const uint32_t *tabs, uint32_t tab_stride, const uint32_t *philox_tab, bool table)
 {
     const auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, philox_tab);
     };
 #ifdef ISINGMC_PKU_TABLE_ALWAYS // A/B builds: the instantiation with table reads for every class
     table = true;
@@ -31,16 +31,25 @@ static void launch_degree(bool uniform_beta, bool mixed_signs, dim3 grid, hipStr
 
 hipError_t pk_uni_launch_sweep(int degree, bool uniform_beta, bool mixed_signs, uint32_t n_groups, hipStream_t stream, uint32_t *state,
                                const PkGraphDev &G, const PkUniHeaders &H, uint32_t class_begin, uint32_t class_end, uint64_t t,
-                               const uint2 *group_keys, const uint32_t *tabs, uint32_t tab_stride, bool needs_table)
+                               const uint2 *group_keys, const uint32_t *tabs, uint32_t tab_stride, const uint32_t *philox_tab, bool needs_table)
 {
     const dim3 grid((class_end - class_begin + 1023) / 1024, n_groups); // 256 threads x 4 positions per workgroup
     switch (degree) {
-    case 3: launch_degree<3>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, needs_table); break;
-    case 4: launch_degree<4>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, needs_table); break;
-    case 5: launch_degree<5>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, needs_table); break;
-    case 6: launch_degree<6>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, needs_table); break;
+    case 3: launch_degree<3>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, philox_tab, needs_table); break;
+    case 4: launch_degree<4>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, philox_tab, needs_table); break;
+    case 5: launch_degree<5>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, philox_tab, needs_table); break;
+    case 6: launch_degree<6>(uniform_beta, mixed_signs, grid, stream, state, G, H, class_begin, class_end, t, group_keys, tabs, tab_stride, philox_tab, needs_table); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+uint32_t pk_uni_philox_table_words() { return PKU_PTAB_WORDS; }
+
+hipError_t pk_uni_launch_philox_table(hipStream_t stream, uint32_t *out, const uint2 *group_keys, uint32_t n_groups, uint64_t t0, uint32_t n_steps)
+{
+    const uint64_t threads = uint64_t(n_steps) * n_groups * PKU_TABLE_CALLS;
+    hipLaunchKernelGGL(pk_philox_table_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, stream, out, group_keys, n_groups, t0, n_steps);
     return hipGetLastError();
 }
 

@@ -80,15 +80,28 @@ __device__ __forceinline__ uint32_t pku_neg_of(const uint2 mask)
 #ifndef ISINGMC_PKU_WAVES
 #define ISINGMC_PKU_WAVES 8 // workgroups of 256 threads per CU the kernel is compiled for (A/B builds: 6 or 5 + ISINGMC_PKU_VKEYS)
 #endif
+// round keys held in vector registers (philox.hpp): what fits under 64 registers without spills (tests/test_build_properties.py) --
+// launches with one beta keep more of their threshold logic in registers than those with one beta per replica
+#ifndef ISINGMC_PKU_NVKEYS
+#define ISINGMC_PKU_NVKEYS 5
+#endif
+#ifndef ISINGMC_PKU_NVKEYS_MIXED_SIGNS
+#define ISINGMC_PKU_NVKEYS_MIXED_SIGNS 3
+#endif
+#ifndef ISINGMC_PKU_NVKEYS_PER_REPLICA
+#define ISINGMC_PKU_NVKEYS_PER_REPLICA 12
+#endif
 #ifndef ISINGMC_PKU_PRE
 #define ISINGMC_PKU_PRE 0
 #endif
 
-#ifdef ISINGMC_PKU_VKEYS // A/B build: round keys 4-10 in vector registers (14 VGPRs; spills at the 64-VGPR cap of 8 waves)
-#define PKU_PHILOX(c) philox4x32_10(c, key, vk)
-#else
-#define PKU_PHILOX(c) philox4x32_10(c, key)
-#endif
+// Philox calls 0 .. PKU_TABLE_CALLS - 1 of a thread (the bit-planes and the first tie call) differ only in counter word 3: their
+// wave-uniform halves come from a table written once per launch (philox.hpp, pk_philox_table_kernel): {S1, S2, S3} of call c in
+// words 3 c .. 3 c + 2, E1 in word PKU_PTAB_E1; PKU_PTAB_WORDS per (timestep, group), 128-byte aligned (wide scalar loads)
+constexpr int PKU_TABLE_CALLS = N_PLANES + 1;
+constexpr uint32_t PKU_PTAB_E1 = 3 * PKU_TABLE_CALLS, PKU_PTAB_USED = PKU_PTAB_E1 + 1, PKU_PTAB_WORDS = 32;
+static_assert(PKU_PTAB_USED <= PKU_PTAB_WORDS, "table layout");
+typedef const __attribute__((address_space(4))) uint32_t pku_const_u32;
 
 // memory phase of the position-quad led by p0.  All 24 block headers first (scalar loads, one wait), then straight-line code: the
 // neighbour's position is own position + the header's shift; where a block is not a translation a branch holding nothing but a
@@ -99,66 +112,70 @@ __device__ __forceinline__ uint32_t pku_neg_of(const uint2 mask)
 typedef const __attribute__((address_space(4))) uint2 pku_const_uint2;
 __device__ __forceinline__ pku_const_uint2 *pku_const(const uint2 *p) { return (pku_const_uint2 *)(uintptr_t)p; }
 
-// Neighbour positions of the position-quad led by p0 from its 24 block headers (scalar loads, one wait): own position + the
-// header's shift; + the exception of a block that is a translation for every lane but one; or -- anything else -- the table entry:
+// Memory phase of the position-quad led by p0 (four blocks of 64 positions, D slots each).
+// A block all of whose slots are plain translations (quad_flags bit clear: nearly every block of a lattice-like graph) issues its
+// D gathers with the own byte offset in the vector register and the header's (biased) shift as the instruction's SCALAR offset:
+// one instruction per neighbour word -- no address arithmetic, no test per slot.  Any other block takes the per-slot code: own
+// offset + shift; + the exception of a slot that is a translation for every lane but one; or -- anything else -- the table entry:
 // a branch holding NOTHING but the load (a use of the loaded value inside the branch, or a header load per slot, would make the wave
-// wait for memory once per slot; this way the first gather waits once for all of them, and for nothing on lattice-like graphs).
-// TABLE = false: the host has checked that no block of the launch needs its table entries (every (block, slot) is a translation,
-// for all lanes or for all but one): no load, no wait, nothing for the compiler to be careful about.
+// wait for memory once per slot; this way the first gather waits once for all of them).
+// TABLE = false: the host has checked that no block of the launch needs its table entries: own words first, no wait in front of the
+// gathers; TABLE = true: own words LAST -- the wait the compiler puts in front of the first gather of a slow block (a table entry
+// may be pending) then finds nothing of ours in flight.
+// nbx_rsrc: the group's state moved DOWN by `bias` = 4 n_pos bytes, unchecked; the headers carry shift + bias >= 0 (a scalar
+// offset is unsigned)
 template <int D, bool TABLE>
-__device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0,
-                                            const uint32_t lane, uint32_t (&ent)[4][PK_MAX_DEG])
-{
-    // ent: BYTE offsets of the neighbour words when TABLE is false (the headers carry their shifts in bytes: no shift per gather),
-    // positions (possibly with a table entry's sign bit) when it is true
-    uint2 h[4][PK_MAX_DEG];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        pku_const_uint2 *hdr = pku_const(H.shift) + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
-#pragma unroll
-        for (int i = 0; i < D; i++) h[q][i] = make_uint2(hdr[i].x, hdr[i].y);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-            const uint32_t hy = uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)); // 4 x the translation
-            if constexpr (TABLE) ent[q][i] = p0 + 64 * q + uint32_t(int32_t(hy) >> 2);
-            else ent[q][i] = 4 * (p0 + 64 * q) + hy;
-        }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-            const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
-            if (hx != PK_HDR_UNIFORM) {
-                asm volatile(""); // (a real scalar branch, skipped by nearly every slot: if-converted, each slot pays ten instructions)
-                const uint32_t e = uint32_t(int32_t(hx) >> 8);
-                if (!TABLE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
-                else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e : 0u;
-                else ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
-            }
-        }
-}
-
-// memory phase of the position-quad led by p0: neighbour positions, the gathers (the shift to a byte offset drops the sign bit of a
-// table entry), and the own words LAST -- the wait the compiler puts in front of the first gather (a table entry may be pending)
-// then finds nothing of ours in flight.  TABLE = false: own words first, byte offsets straight from the headers.
-template <int D, bool TABLE>
-__device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H,
-                                         const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
+__device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t nbx_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc,
+                                         const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
                                          uint32_t (&nb)[4][PK_MAX_DEG])
 {
-    uint32_t ent[4][PK_MAX_DEG];
-    if constexpr (!TABLE) { // nothing to wait for before the gathers: the own words go first (they need no header)
+    const uint32_t bias = 4u * n_pos;
+    if constexpr (!TABLE) {
 #pragma unroll
         for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
     }
-    pku_resolve<D, TABLE>(ell_rsrc, H, n_pos, p0, lane, ent);
+    const uint32_t quad = uint32_t(__builtin_amdgcn_readfirstlane(p0 >> 8)); // wave-uniform
+    const uint32_t slow = *((pku_const_u32 *)(uintptr_t)H.quad_flags + quad);
+    uint2 h[4][PK_MAX_DEG];
 #pragma unroll
-    for (int i = 0; i < D; i++)
+    for (int q = 0; q < 4; q++) {
+        pku_const_uint2 *hdr = pku_const(H.shift) + (size_t(quad) * 4 + q) * PK_MAX_DEG;
 #pragma unroll
-        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, TABLE ? ent[q][i] << 2 : ent[q][i], 0, 0);
+        for (int i = 0; i < D; i++) h[q][i] = make_uint2(hdr[i].x, hdr[i].y);
+    }
+    // (the very first word is used by the per-slot code only: unpinned, the compiler reads it THERE, and waits for it)
+    asm volatile("" : "+s"(h[0][0].x));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t own_off = 4 * (p0 + 64 * q);
+        if (!((slow >> q) & 1u)) {
+#pragma unroll
+            for (int i = 0; i < D; i++)
+                nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(nbx_rsrc, own_off, uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)), 0);
+        } else {
+            asm volatile(""); // (a real scalar branch)
+            uint32_t ent[PK_MAX_DEG]; // byte offsets into nbx_rsrc (TABLE: positions until the end, where a table entry's sign bit is shifted out)
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                const uint32_t hy = uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)); // 4 x the translation + bias
+                if constexpr (TABLE) ent[i] = p0 + 64 * q + uint32_t(int32_t(hy - bias) >> 2);
+                else ent[i] = own_off + hy;
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
+                if (hx != PK_HDR_UNIFORM) {
+                    asm volatile(""); // (a real scalar branch: if-converted, each slot pays ten instructions)
+                    const uint32_t e = uint32_t(int32_t(hx) >> 8);
+                    if (!TABLE) ent[i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
+                    else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[i] += lane == ((hx >> 2) & 63u) ? e : 0u;
+                    else ent[i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(nbx_rsrc, TABLE ? (ent[i] << 2) + bias : ent[i], 0, 0);
+        }
+    }
     if constexpr (TABLE) {
 #pragma unroll
         for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
@@ -168,7 +185,7 @@ __device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, c
 // classes of the position-quad led by p0 from its own and neighbour words: eq[q][j] = the replicas with k_j satisfied bonds,
 // sure = flips whatever the random numbers say, und = costly and not yet decided
 template <int D, bool PMJ>
-__device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_t p0, const uint32_t *__restrict__ tab, const uint32_t (&own)[4],
+__device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_t p0, pku_const_u32 *tab, const uint32_t (&own)[4],
                                             const uint32_t (&nb)[4][PK_MAX_DEG], uint32_t (&eq)[4][3], uint32_t (&sure)[4], uint32_t (&und)[4])
 {
     using CL = PkuClasses<D>;
@@ -180,9 +197,14 @@ __device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_
     for (int q = 0; q < 4; q++) {
         uint32_t sat[PK_MAX_DEG], c0, c1, c2;
         pku_const_uint2 *signs = pku_const(H.sign) + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG;
+        // J > 0: satisfied when the spins differ.  One sign: it is folded into the own word once (a three-input xor with a scalar
+        // source issues at half the rate of a two-input one on vector registers: 24 of them per wave)
+        const uint32_t own_signed = PMJ ? own[q] : own[q] ^ H.negmask;
 #pragma unroll
-        for (int i = 0; i < D; i++) // J > 0: satisfied when the spins differ
-            sat[i] = pku_xor3(own[q], nb[q][i], PMJ ? pku_neg_of(make_uint2(signs[i].x, signs[i].y)) : H.negmask);
+        for (int i = 0; i < D; i++) {
+            if constexpr (PMJ) sat[i] = pku_xor3(own[q], nb[q][i], pku_neg_of(make_uint2(signs[i].x, signs[i].y)));
+            else sat[i] = own_signed ^ nb[q][i];
+        }
         pku_count<D>(sat, c0, c1, c2);
         eq[q][0] = pku_match<CL::k(0)>(c0, c1, c2);
         eq[q][1] = pku_match<CL::k(1)>(c0, c1, c2);
@@ -197,33 +219,33 @@ __device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_
 }
 
 // the random half: bit-planes of the acceptance uniform against the classes' thresholds, then the ties; acc[q] = the replica bits that flip
-template <int D, bool UB>
-__device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, const uint2 key,
-#ifdef ISINGMC_PKU_VKEYS
-                                           const PhiloxVKeys &vk,
-#endif
-                                           const uint32_t *__restrict__ tab, const uint32_t (&eq)[4][3], const uint32_t (&sure)[4],
-                                           uint32_t (&und)[4], uint32_t (&acc)[4])
+template <int D, bool UB, bool PMJ>
+__device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, const uint2 key, const uint32_t (&pt)[PKU_PTAB_USED],
+                                           const uint32_t (&selw)[2], pku_const_u32 *tab, const uint32_t (&eq)[4][3],
+                                           const uint32_t (&sure)[4], uint32_t (&und)[4], uint32_t (&acc)[4])
 {
     using CL = PkuClasses<D>;
     constexpr int NJ = CL::NJ;
     // The random words do not depend on the spins: the first ISINGMC_PKU_PRE planes are drawn here, between the issue of the
     // gathers and the first use of their results, so that the memory round trip is covered by arithmetic of the wave's own
     const uint32_t c0w = uint32_t(t), c1w = p0;
+    const PhiloxShared sh = philox_shared(c1w, DOM_PK_SWEEP, key, pt[PKU_PTAB_E1]);
+    constexpr int NV = !UB ? ISINGMC_PKU_NVKEYS_PER_REPLICA : PMJ ? ISINGMC_PKU_NVKEYS_MIXED_SIGNS : ISINGMC_PKU_NVKEYS;
+    const PhiloxSomeVKeys<NV> vk = philox_some_vkeys<NV>(key);
+    const auto draw = [&](const int call) { return philox4x32_10_late(sh, pt[3 * call], pt[3 * call + 1], pt[3 * call + 2], key, vk); };
     uint4 pre[ISINGMC_PKU_PRE > 0 ? ISINGMC_PKU_PRE : 1];
 #pragma unroll
     for (int k = 0; k < ISINGMC_PKU_PRE; k++) {
-        pre[k] = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES - 1 - k)));
+        pre[k] = draw(N_PLANES - 1 - k);
         asm volatile("" : "+v"(pre[k].x), "+v"(pre[k].y), "+v"(pre[k].z), "+v"(pre[k].w));
     }
     uint32_t lt[4] = {0, 0, 0, 0};
-    uint32_t selw[2] = {0, 0}; // UB: which classes' threshold bits are set in each plane, from two table words (not 21 loads)
-    if constexpr (UB) { selw[0] = tab[PK_TAB_SEL]; selw[1] = tab[PK_TAB_SEL + 1]; }
+    // (selw -- UB: which classes' threshold bits are set in each plane, from two table words, not 21 loads)
     // bit-planes, least significant first: lt' = (~r & tb) | (~(r ^ tb) & lt), und' = und & ~(r ^ tb)
 #pragma unroll
     for (int pl = N_PLANES - 1; pl >= 0; pl--) {
         const uint4 rnd = N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? pre[N_PLANES - 1 - pl < ISINGMC_PKU_PRE ? N_PLANES - 1 - pl : 0]
-                                                              : PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, pl)));
+                                                              : draw(pl);
         const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
         uint32_t T[3] = {0, 0, 0};
         if constexpr (UB) { // bit row * N_PLANES + pl of the two selection words: is this plane's bit of the row's threshold set?
@@ -279,7 +301,7 @@ __device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, 
     for (int q = 0; q < 4; q++) acc[q] = sure[q] | lt[q];
     if (und[0] | und[1] | und[2] | und[3]) { // ties: n-th of the position-quad takes word n%4 of call N_PLANES + n/4
         uint32_t nres = 0;
-        uint4 rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES)));
+        uint4 rnd = draw(N_PLANES);
         uint32_t lo_j[3] = {0, 0, 0};
         if constexpr (UB) {
 #pragma unroll
@@ -292,7 +314,7 @@ __device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, 
                 const uint32_t b = __ffs(mm) - 1;
                 mm &= mm - 1;
                 if (nres != 0 && (nres & 3u) == 0)
-                    rnd = PKU_PHILOX(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES + (nres >> 2))));
+                    rnd = philox4x32_10(make_uint4(c0w, c1w, DOM_PK_SWEEP, ctr2(t, 0, N_PLANES + (nres >> 2))), key); // (rare: a fifth tie)
                 const bool is0 = (eq[q][0] >> b) & 1u, is1 = (eq[q][1] >> b) & 1u;
                 uint32_t lo;
                 if constexpr (UB) lo = is0 ? lo_j[0] : is1 ? lo_j[1] : lo_j[2];
@@ -307,53 +329,87 @@ __device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, 
 
 // decisions of the position-quad led by p0 from its own and neighbour words; acc[q] = the replica bits that flip
 template <int D, bool UB, bool PMJ>
-__device__ __forceinline__ void pku_decide(const PkUniHeaders &H, const uint32_t p0, const uint64_t t, const uint2 key,
-#ifdef ISINGMC_PKU_VKEYS
-                                           const PhiloxVKeys &vk,
-#endif
-                                           const uint32_t *__restrict__ tab, const uint32_t (&own)[4], const uint32_t (&nb)[4][PK_MAX_DEG],
+__device__ __forceinline__ void pku_decide(const PkUniHeaders &H, const uint32_t p0, const uint64_t t, const uint2 key, pku_const_u32 *ptab,
+                                           pku_const_u32 *tab, const uint32_t (&own)[4], const uint32_t (&nb)[4][PK_MAX_DEG],
                                            uint32_t (&acc)[4])
 {
     uint32_t eq[4][3], sure[4], und[4];
-    pku_classes<D, PMJ>(H, p0, tab, own, nb, eq, sure, und);
-#ifdef ISINGMC_PKU_VKEYS
-    pku_random<D, UB>(p0, t, key, vk, tab, eq, sure, und, acc);
-#else
-    pku_random<D, UB>(p0, t, key, tab, eq, sure, und, acc);
-#endif
+    // the table words: ONE bulk scalar read issued here, behind the gathers, and pinned behind the classes -- left to itself the compiler
+    // reads three words in front of every call and waits for them on the spot (seven exposed scalar round trips per wave)
+    // Couplings of both signs: the classes read 48 sign words per wave through the scalar unit as well -- no room for the table next
+    // to them (scalar registers spilled into vector lanes); there the table is read behind the classes (one exposed read, not seven)
+    uint32_t pt[PKU_PTAB_USED];
+    uint64_t sel64 = 0; // (the two selection words as one register pair: pinned word by word, the second is copied -- behind a wait)
+    if constexpr (PMJ) {
+        pku_classes<D, PMJ>(H, p0, tab, own, nb, eq, sure, und);
+        uint64_t bits = uint64_t(uintptr_t(ptab));
+        asm volatile("" : "+s"(bits) : "v"(und[0]), "v"(und[1]), "v"(und[2]), "v"(und[3])); // (the address "depends" on the classes)
+        ptab = (pku_const_u32 *)uintptr_t(uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(bits >> 32)))) << 32 |
+                                          uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(bits))));
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PKU_PTAB_USED; i++) pt[i] = ptab[i];
+    if constexpr (UB) sel64 = uint64_t(tab[PK_TAB_SEL]) | uint64_t(tab[PK_TAB_SEL + 1]) << 32;
+    if constexpr (!PMJ) pku_classes<D, PMJ>(H, p0, tab, own, nb, eq, sure, und);
+    if constexpr (UB) asm volatile("" : "+s"(sel64) : "v"(und[0]), "v"(und[1]), "v"(und[2]), "v"(und[3]));
+    const uint32_t selw[2] = {uint32_t(sel64), uint32_t(sel64 >> 32)};
+#pragma unroll
+    for (uint32_t i = 0; i < PKU_PTAB_USED; i++)
+        asm volatile("" : "+s"(pt[i]) : "v"(und[0]), "v"(und[1]), "v"(und[2]), "v"(und[3])); // (inputs: the classes' results -- the pin cannot move up)
+    pku_random<D, UB, PMJ>(p0, t, key, pt, selw, tab, eq, sure, und, acc);
 }
 
 template <int D, bool UB, bool PMJ, bool TABLE>
 __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(uint32_t *__restrict__ state, const PkGraphDev G, const PkUniHeaders H,
                                                                const uint32_t class_begin, const uint32_t class_end,
                                                                const uint64_t t, const uint2 *__restrict__ group_keys,
-                                                               const uint32_t *__restrict__ tabs, const uint32_t tab_stride)
+                                                               const uint32_t *__restrict__ tabs, const uint32_t tab_stride,
+                                                               const uint32_t *__restrict__ philox_tab)
 {
     const uint32_t g = blockIdx.y;
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x; // wave w of the class owns positions [256 w, 256 w + 256)
     const uint32_t p0 = class_begin + 256 * (tid >> 6) + (tid & 63u); // the quad's leader
     if (p0 >= class_end) return;
     uint32_t *st = state + size_t(g) * G.n_pos;
-    const uint32_t *tab = tabs + size_t(g) * tab_stride;
     const uint2 key = group_keys[g];
-#ifdef ISINGMC_PKU_VKEYS
-    const PhiloxVKeys vk = philox_vkeys(key);
-#define PKU_VK vk,
-#else
-#define PKU_VK
-#endif
+    // this group's tables (and the one sign), pinned HERE: left to the compiler, the kernel arguments behind them are read where they
+    // are first used -- behind the gathers, with a wait that also holds back the table reads
+    const uint64_t tab_bits = uint64_t(uintptr_t(tabs + size_t(g) * tab_stride)), ptab_bits = uint64_t(uintptr_t(philox_tab + size_t(g) * PKU_PTAB_WORDS));
+    uint32_t pin[5] = {uint32_t(tab_bits), uint32_t(tab_bits >> 32), uint32_t(ptab_bits), uint32_t(ptab_bits >> 32), H.negmask};
+    if constexpr (!TABLE) // (with table entries the memory phase has no scalar registers to spare: there the arguments are read late)
+        asm volatile("" : "+s"(pin[0]), "+s"(pin[1]), "+s"(pin[2]), "+s"(pin[3]), "+s"(pin[4]));
+#pragma unroll
+    for (int i = 0; i < 5; i++) pin[i] = uint32_t(__builtin_amdgcn_readfirstlane(pin[i])); // (uniform: no instruction)
+    pku_const_u32 *tab = (pku_const_u32 *)uintptr_t(uint64_t(pin[1]) << 32 | pin[0]);
+    pku_const_u32 *ptab = (pku_const_u32 *)uintptr_t(uint64_t(pin[3]) << 32 | pin[2]); // this timestep's, this group's
+    PkUniHeaders Hp = H;
+    Hp.negmask = pin[4];
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t nbx_rsrc = __builtin_amdgcn_make_buffer_rsrc(st - G.n_pos, 0, -1, 0x00020000); // (pku_load)
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
 
     uint32_t own[4], nb[4][PK_MAX_DEG], acc[4];
-    pku_load<D, TABLE>(st_rsrc, ell_rsrc, H, G.n_pos, p0, tid & 63u, own, nb);
-    pku_decide<D, UB, PMJ>(H, p0, t, key, PKU_VK tab, own, nb, acc);
+    pku_load<D, TABLE>(st_rsrc, nbx_rsrc, ell_rsrc, Hp, G.n_pos, p0, tid & 63u, own, nb);
+    pku_decide<D, UB, PMJ>(Hp, p0, t, key, ptab, tab, own, nb, acc);
 #pragma unroll
     for (int q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(own[q] ^ acc[q], st_rsrc, 4 * (p0 + 64 * q), 0, 0);
-#undef PKU_VK
 }
 
-#undef PKU_PHILOX
+// the wave-uniform words of the table calls of timesteps t0 .. t0 + n_steps - 1 for every group: out[(k n_groups + g) PKU_PTAB_WORDS + 3 call + i]
+__attribute__((unused)) static __global__ void pk_philox_table_kernel(uint32_t *__restrict__ out, const uint2 *__restrict__ group_keys,
+                                                                      const uint32_t n_groups, const uint64_t t0, const uint32_t n_steps)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t call = idx % PKU_TABLE_CALLS, g = (idx / PKU_TABLE_CALLS) % n_groups, k = idx / PKU_TABLE_CALLS / n_groups;
+    if (k >= n_steps) return;
+    const uint64_t t = t0 + k;
+    const PhiloxUniform u = philox_uniform_words(uint32_t(t), DOM_PK_SWEEP, ctr2(t, 0, call), group_keys[g]);
+    uint32_t *o = out + (size_t(k) * n_groups + g) * PKU_PTAB_WORDS;
+    o[3 * call] = u.s1;
+    o[3 * call + 1] = u.s2;
+    o[3 * call + 2] = u.s3;
+    if (call == 0) o[PKU_PTAB_E1] = u.e1;
+}
 
 } // namespace isingmc

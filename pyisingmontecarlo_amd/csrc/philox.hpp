@@ -47,6 +47,87 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
     return c;
 }
 
+// ---- calls that differ only in counter word 3 (and whose word 1 is the only lane-varying input) ----------------------------
+// Rounds 1-3 of such calls, spelled out (M0, M1 the multipliers; W0, W1 the key increments; c = (c0, c1, c2, c3), key (kx, ky)):
+//   A = M0 c0, B = M1 c2                                  -> (B.hi ^ c1 ^ kx, B.lo, A.hi ^ c3 ^ ky, A.lo)
+//   P = M0 (c1 ^ E0), Q = M1 (A.hi ^ c3 ^ ky)             -> (Q.hi ^ B.lo ^ kx', Q.lo, P.hi ^ E1, P.lo)        E0 = B.hi ^ kx, E1 = A.lo ^ ky'
+//   U = M0 (Q.hi ^ B.lo ^ kx'), V = M1 (P.hi ^ E1)        -> (V.hi ^ S1, V.lo, P.lo ^ S2, S3)       S1 = Q.lo ^ kx'', S2 = U.hi ^ ky'', S3 = U.lo
+// P and V are the only lane-varying products and do not depend on c3: a thread that draws several calls computes them once
+// (philox_shared).  Everything else is wave-uniform AND the same for every wave of a launch: per (key, c0, c2, c3) the three words
+// S1, S2, S3 plus E1 -- philox_uniform_words, run once per launch by a table kernel instead of once per wave on the scalar unit
+// (12 scalar instructions per call; the one-degree packed kernel draws 8 calls per wave and is bound by instruction issue).
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u, PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+
+struct PhiloxUniform {
+    uint32_t s1, s2, s3, e1;
+};
+
+__host__ __device__ inline PhiloxUniform philox_uniform_words(uint32_t c0, uint32_t c2, uint32_t c3, uint2 key)
+{
+    const uint64_t A = uint64_t(PHILOX_M0) * c0, B = uint64_t(PHILOX_M1) * c2;
+    const uint64_t Q = uint64_t(PHILOX_M1) * (uint32_t(A >> 32) ^ c3 ^ key.y);
+    const uint64_t U = uint64_t(PHILOX_M0) * (uint32_t(Q >> 32) ^ uint32_t(B) ^ (key.x + PHILOX_W0));
+    PhiloxUniform u;
+    u.s1 = uint32_t(Q) ^ (key.x + 2u * PHILOX_W0);
+    u.s2 = uint32_t(U >> 32) ^ (key.y + 2u * PHILOX_W1);
+    u.s3 = uint32_t(U);
+    u.e1 = uint32_t(A) ^ (key.y + PHILOX_W1);
+    return u;
+}
+
+struct PhiloxShared {
+    uint32_t p_lo, v_hi, v_lo;
+};
+
+// c2 is a compile-time constant at every call site (the domain word): B folds away
+__device__ __forceinline__ PhiloxShared philox_shared(uint32_t c1, uint32_t c2, uint2 key, uint32_t e1)
+{
+    const uint32_t e0 = uint32_t((uint64_t(PHILOX_M1) * c2) >> 32) ^ key.x;
+    const uint64_t P = uint64_t(PHILOX_M0) * (c1 ^ e0);
+    const uint64_t V = uint64_t(PHILOX_M1) * (uint32_t(P >> 32) ^ e1);
+    return PhiloxShared{uint32_t(P), uint32_t(V >> 32), uint32_t(V)};
+}
+
+// The first NV of the 14 round keys of rounds 4-10 (x of round 4, y of round 4, x of round 5, ...) in VECTOR registers: a v_bitop3
+// with a scalar source issues at half the rate of one on vector registers (tools/ubench/valu_forms.hip), and a thread that draws
+// eight calls uses every key eight times.  As many as the kernel's register budget leaves room for.
+template <int NV>
+struct PhiloxSomeVKeys {
+    uint32_t k[NV > 0 ? NV : 1];
+};
+
+template <int NV>
+__device__ __forceinline__ PhiloxSomeVKeys<NV> philox_some_vkeys(uint2 key)
+{
+    PhiloxSomeVKeys<NV> v;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t x = i % 2 == 0 ? key.x + uint32_t(i / 2 + 3) * PHILOX_W0 : key.y + uint32_t(i / 2 + 3) * PHILOX_W1;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v.k[i]) : "s"(x)); // (inline asm: the compiler cannot fold the scalar back into the uses)
+    }
+    return v;
+}
+
+// rounds 4-10 of the call whose uniform words are (s1, s2, s3)
+template <int NV>
+__device__ __forceinline__ uint4 philox4x32_10_late(const PhiloxShared &sh, uint32_t s1, uint32_t s2, uint32_t s3, uint2 key, const PhiloxSomeVKeys<NV> &vk)
+{
+    uint4 c = make_uint4(sh.v_hi ^ s1, sh.v_lo, sh.p_lo ^ s2, s3);
+#ifdef ISINGMC_TIMING_ONLY_CHEAP_RNG
+    return c;
+#endif
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint64_t p0 = uint64_t(PHILOX_M0) * c.x;
+        const uint64_t p1 = uint64_t(PHILOX_M1) * c.z;
+        const uint32_t kx = 2 * r < NV ? vk.k[2 * r < NV ? 2 * r : 0] : key.x + uint32_t(r + 3) * PHILOX_W0;
+        const uint32_t ky = 2 * r + 1 < NV ? vk.k[2 * r + 1 < NV ? 2 * r + 1 : 0] : key.y + uint32_t(r + 3) * PHILOX_W1;
+        c = make_uint4(__builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c.y, kx, 0x96), uint32_t(p1),
+                       __builtin_amdgcn_bitop3_b32(uint32_t(p0 >> 32), c.w, ky, 0x96), uint32_t(p0));
+    }
+    return c;
+}
+
 // The round keys of rounds 4-10 in VECTOR registers.  Measured on gfx950 (tools/ubench/valu_forms.hip): a VALU
 // instruction with an SGPR source issues in 4.3 cycles per wave, the same instruction on VGPRs only in 2.5
 // (v_xor, v_and, v_add, v_bitop3, shifts; everything else -- multiplies, v_and_or, v_alignbit, v_cndmask -- is
