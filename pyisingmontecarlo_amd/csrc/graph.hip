@@ -447,8 +447,7 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
             for (size_t i = 0; i < nvars; i++) mindeg = std::min(mindeg, A.ptr[i + 1] - A.ptr[i]);
             bool one_sign = true;
             for (double x : w) one_sign &= (x > 0.0) == (w[0] > 0.0);
-            // (12 n_pos < 2^32: own byte offset + biased shift + exception stay inside 32 bits, packed_types.hpp)
-            if (mindeg == maxdeg && maxdeg >= 3 && 12ull * n_pos < (1ull << 32)) {
+            if (mindeg == maxdeg && maxdeg >= 3) {
                 g->pk_uni_deg = int(maxdeg);
                 g->pk_uni_pmj = !one_sign;
                 g->pk_uni.negmask = w[0] > 0.0 ? 0u : 0xFFFFFFFFu;
@@ -468,22 +467,16 @@ static int build_general(isingmc_graph *g, const uint64_t *ea, const uint64_t *e
                             mask |= uint64_t(e[l] != PK_NO_NBR && (e[l] >> 31)) << l;
                         }
                         // (the one-degree kernels' headers carry the translation in BYTES: 4 x delta fits, the state of a group is below 2^31 bytes)
-                        const uint32_t bias = 4u * uint32_t(n_pos);
-                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, 4u * delta + bias);
+                        if (odd_lanes == 0) shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM, 4u * delta);
                         else if (odd_lanes == 1 && e[odd_lane] != PK_NO_NBR) { // a translation but for one lane (a row's wrap-around)
                             const int32_t ex = int32_t(off(odd_lane) - delta);
                             if (ex >= -(1 << 23) && ex < (1 << 23))
-                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), 4u * delta + bias);
+                                shift[B * PK_MAX_DEG + i] = make_uint2(PK_HDR_UNIFORM_BUT_ONE | (odd_lane << 2) | (uint32_t(ex) << 8), 4u * delta);
                         }
                         sign[B * PK_MAX_DEG + i] = make_uint2(uint32_t(mask), uint32_t(mask >> 32));
                     }
                 });
                 for (const uint2 &hd : shift) g->pk_uni_but_one += (hd.x & 3u) == PK_HDR_UNIFORM_BUT_ONE && hd.x != PK_HDR_UNIFORM;
-                std::vector<uint32_t> quad_flags(n_blocks / 4, 0u);
-                for (size_t B = 0; B < n_blocks; B++)
-                    for (uint32_t i = 0; i < uint32_t(maxdeg); i++)
-                        if (shift[B * PK_MAX_DEG + i].x != PK_HDR_UNIFORM) quad_flags[B / 4] |= 1u << (B % 4);
-                TRY(graph_upload(g, &g->pk_uni.quad_flags, quad_flags));
                 TRY(graph_upload(g, &g->pk_uni.shift, shift));
                 TRY(graph_upload(g, &g->pk_uni.sign, sign));
                 g->pk_class_full.resize(C.n_colours);

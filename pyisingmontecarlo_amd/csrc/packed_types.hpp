@@ -44,13 +44,9 @@ struct PkGraphDev {
 //                 dependent table read before the gathers could be issued (round 4: +8 %);
 //                 else {PK_HDR_MIXED, 0}: addresses from nbr_ell;
 //   sign[B][i]  = bit l set <=> the slot-i bond of position 64 B + l has J > 0 (only read when the signs differ)
-//   quad_flags[Q] bit q set <=> some slot of block 4 Q + q is NOT {PK_HDR_UNIFORM, ...} (the block takes the per-slot code)
-// The shifts are stored BIASED by 4 n_pos bytes (never negative): the kernels use them as the scalar offset of a buffer load,
-// which is unsigned, against a base moved down by the same amount.
 struct PkUniHeaders {
     const uint2 *shift;
     const uint2 *sign;
-    const uint32_t *quad_flags; // [n_pos / 256]
     uint32_t negmask; // one sign for every bond: 0 (J > 0) or ~0 (J < 0)
 };
 

@@ -78,18 +78,7 @@ __device__ __forceinline__ uint32_t pku_neg_of(const uint2 mask)
 }
 
 #ifndef ISINGMC_PKU_WAVES
-#define ISINGMC_PKU_WAVES 8 // workgroups of 256 threads per CU the kernel is compiled for (A/B builds: 6 or 5 + ISINGMC_PKU_VKEYS)
-#endif
-// round keys held in vector registers (philox.hpp): what fits under 64 registers without spills (tests/test_build_properties.py) --
-// launches with one beta keep more of their threshold logic in registers than those with one beta per replica
-#ifndef ISINGMC_PKU_NVKEYS
-#define ISINGMC_PKU_NVKEYS 5
-#endif
-#ifndef ISINGMC_PKU_NVKEYS_MIXED_SIGNS
-#define ISINGMC_PKU_NVKEYS_MIXED_SIGNS 3
-#endif
-#ifndef ISINGMC_PKU_NVKEYS_PER_REPLICA
-#define ISINGMC_PKU_NVKEYS_PER_REPLICA 12
+#define ISINGMC_PKU_WAVES 8 // workgroups of 256 threads per CU the kernel is compiled for (A/B builds: 6 or 5)
 #endif
 #ifndef ISINGMC_PKU_PRE
 #define ISINGMC_PKU_PRE 0
@@ -112,70 +101,66 @@ typedef const __attribute__((address_space(4))) uint32_t pku_const_u32;
 typedef const __attribute__((address_space(4))) uint2 pku_const_uint2;
 __device__ __forceinline__ pku_const_uint2 *pku_const(const uint2 *p) { return (pku_const_uint2 *)(uintptr_t)p; }
 
-// Memory phase of the position-quad led by p0 (four blocks of 64 positions, D slots each).
-// A block all of whose slots are plain translations (quad_flags bit clear: nearly every block of a lattice-like graph) issues its
-// D gathers with the own byte offset in the vector register and the header's (biased) shift as the instruction's SCALAR offset:
-// one instruction per neighbour word -- no address arithmetic, no test per slot.  Any other block takes the per-slot code: own
-// offset + shift; + the exception of a slot that is a translation for every lane but one; or -- anything else -- the table entry:
+// Neighbour positions of the position-quad led by p0 from its 24 block headers (scalar loads, one wait): own position + the
+// header's shift; + the exception of a block that is a translation for every lane but one; or -- anything else -- the table entry:
 // a branch holding NOTHING but the load (a use of the loaded value inside the branch, or a header load per slot, would make the wave
-// wait for memory once per slot; this way the first gather waits once for all of them).
-// TABLE = false: the host has checked that no block of the launch needs its table entries: own words first, no wait in front of the
-// gathers; TABLE = true: own words LAST -- the wait the compiler puts in front of the first gather of a slow block (a table entry
-// may be pending) then finds nothing of ours in flight.
-// nbx_rsrc: the group's state moved DOWN by `bias` = 4 n_pos bytes, unchecked; the headers carry shift + bias >= 0 (a scalar
-// offset is unsigned)
+// wait for memory once per slot; this way the first gather waits once for all of them, and for nothing on lattice-like graphs).
+// TABLE = false: the host has checked that no block of the launch needs its table entries (every (block, slot) is a translation,
+// for all lanes or for all but one): no load, no wait, nothing for the compiler to be careful about.
 template <int D, bool TABLE>
-__device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t nbx_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc,
-                                         const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
-                                         uint32_t (&nb)[4][PK_MAX_DEG])
+__device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H, const uint32_t n_pos, const uint32_t p0,
+                                            const uint32_t lane, uint32_t (&ent)[4][PK_MAX_DEG])
 {
-    const uint32_t bias = 4u * n_pos;
-    if constexpr (!TABLE) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
-    }
-    const uint32_t quad = uint32_t(__builtin_amdgcn_readfirstlane(p0 >> 8)); // wave-uniform
-    const uint32_t slow = *((pku_const_u32 *)(uintptr_t)H.quad_flags + quad);
+    // ent: BYTE offsets of the neighbour words when TABLE is false (the headers carry their shifts in bytes: no shift per gather),
+    // positions (possibly with a table entry's sign bit) when it is true
     uint2 h[4][PK_MAX_DEG];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        pku_const_uint2 *hdr = pku_const(H.shift) + (size_t(quad) * 4 + q) * PK_MAX_DEG;
+        pku_const_uint2 *hdr = pku_const(H.shift) + size_t(__builtin_amdgcn_readfirstlane((p0 + 64 * q) >> 6)) * PK_MAX_DEG; // wave-uniform
 #pragma unroll
         for (int i = 0; i < D; i++) h[q][i] = make_uint2(hdr[i].x, hdr[i].y);
     }
-    // (the very first word is used by the per-slot code only: unpinned, the compiler reads it THERE, and waits for it)
-    asm volatile("" : "+s"(h[0][0].x));
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t own_off = 4 * (p0 + 64 * q);
-        if (!((slow >> q) & 1u)) {
+    for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int i = 0; i < D; i++)
-                nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(nbx_rsrc, own_off, uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)), 0);
-        } else {
-            asm volatile(""); // (a real scalar branch)
-            uint32_t ent[PK_MAX_DEG]; // byte offsets into nbx_rsrc (TABLE: positions until the end, where a table entry's sign bit is shifted out)
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                const uint32_t hy = uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)); // 4 x the translation + bias
-                if constexpr (TABLE) ent[i] = p0 + 64 * q + uint32_t(int32_t(hy - bias) >> 2);
-                else ent[i] = own_off + hy;
-            }
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
-                if (hx != PK_HDR_UNIFORM) {
-                    asm volatile(""); // (a real scalar branch: if-converted, each slot pays ten instructions)
-                    const uint32_t e = uint32_t(int32_t(hx) >> 8);
-                    if (!TABLE) ent[i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
-                    else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[i] += lane == ((hx >> 2) & 63u) ? e : 0u;
-                    else ent[i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < D; i++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(nbx_rsrc, TABLE ? (ent[i] << 2) + bias : ent[i], 0, 0);
+        for (int i = 0; i < D; i++) {
+            const uint32_t hy = uint32_t(__builtin_amdgcn_readfirstlane(h[q][i].y)); // 4 x the translation
+            if constexpr (TABLE) ent[q][i] = p0 + 64 * q + uint32_t(int32_t(hy) >> 2);
+            else ent[q][i] = 4 * (p0 + 64 * q) + hy;
         }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
+            if (hx != PK_HDR_UNIFORM) {
+                asm volatile(""); // (a real scalar branch, skipped by nearly every slot: if-converted, each slot pays ten instructions)
+                const uint32_t e = uint32_t(int32_t(hx) >> 8);
+                if (!TABLE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
+                else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e : 0u;
+                else ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
+            }
+        }
+}
+
+// memory phase of the position-quad led by p0: neighbour positions, the gathers (the shift to a byte offset drops the sign bit of a
+// table entry), and the own words LAST -- the wait the compiler puts in front of the first gather (a table entry may be pending)
+// then finds nothing of ours in flight.  TABLE = false: own words first, byte offsets straight from the headers.
+template <int D, bool TABLE>
+__device__ __forceinline__ void pku_load(const __amdgpu_buffer_rsrc_t st_rsrc, const __amdgpu_buffer_rsrc_t ell_rsrc, const PkUniHeaders &H,
+                                         const uint32_t n_pos, const uint32_t p0, const uint32_t lane, uint32_t (&own)[4],
+                                         uint32_t (&nb)[4][PK_MAX_DEG])
+{
+    uint32_t ent[4][PK_MAX_DEG];
+    if constexpr (!TABLE) { // nothing to wait for before the gathers: the own words go first (they need no header)
+#pragma unroll
+        for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
     }
+    pku_resolve<D, TABLE>(ell_rsrc, H, n_pos, p0, lane, ent);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) nb[q][i] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, TABLE ? ent[q][i] << 2 : ent[q][i], 0, 0);
     if constexpr (TABLE) {
 #pragma unroll
         for (int q = 0; q < 4; q++) own[q] = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, 4 * (p0 + 64 * q), 0, 0);
@@ -219,7 +204,7 @@ __device__ __forceinline__ void pku_classes(const PkUniHeaders &H, const uint32_
 }
 
 // the random half: bit-planes of the acceptance uniform against the classes' thresholds, then the ties; acc[q] = the replica bits that flip
-template <int D, bool UB, bool PMJ>
+template <int D, bool UB>
 __device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, const uint2 key, const uint32_t (&pt)[PKU_PTAB_USED],
                                            const uint32_t (&selw)[2], pku_const_u32 *tab, const uint32_t (&eq)[4][3],
                                            const uint32_t (&sure)[4], uint32_t (&und)[4], uint32_t (&acc)[4])
@@ -230,9 +215,7 @@ __device__ __forceinline__ void pku_random(const uint32_t p0, const uint64_t t, 
     // gathers and the first use of their results, so that the memory round trip is covered by arithmetic of the wave's own
     const uint32_t c0w = uint32_t(t), c1w = p0;
     const PhiloxShared sh = philox_shared(c1w, DOM_PK_SWEEP, key, pt[PKU_PTAB_E1]);
-    constexpr int NV = !UB ? ISINGMC_PKU_NVKEYS_PER_REPLICA : PMJ ? ISINGMC_PKU_NVKEYS_MIXED_SIGNS : ISINGMC_PKU_NVKEYS;
-    const PhiloxSomeVKeys<NV> vk = philox_some_vkeys<NV>(key);
-    const auto draw = [&](const int call) { return philox4x32_10_late(sh, pt[3 * call], pt[3 * call + 1], pt[3 * call + 2], key, vk); };
+    const auto draw = [&](const int call) { return philox4x32_10_late(sh, pt[3 * call], pt[3 * call + 1], pt[3 * call + 2], key); };
     uint4 pre[ISINGMC_PKU_PRE > 0 ? ISINGMC_PKU_PRE : 1];
 #pragma unroll
     for (int k = 0; k < ISINGMC_PKU_PRE; k++) {
@@ -356,7 +339,7 @@ __device__ __forceinline__ void pku_decide(const PkUniHeaders &H, const uint32_t
 #pragma unroll
     for (uint32_t i = 0; i < PKU_PTAB_USED; i++)
         asm volatile("" : "+s"(pt[i]) : "v"(und[0]), "v"(und[1]), "v"(und[2]), "v"(und[3])); // (inputs: the classes' results -- the pin cannot move up)
-    pku_random<D, UB, PMJ>(p0, t, key, pt, selw, tab, eq, sure, und, acc);
+    pku_random<D, UB>(p0, t, key, pt, selw, tab, eq, sure, und, acc);
 }
 
 template <int D, bool UB, bool PMJ, bool TABLE>
@@ -372,26 +355,15 @@ __global__ __launch_bounds__(256, ISINGMC_PKU_WAVES) void pk_sweep_uni_kernel(ui
     if (p0 >= class_end) return;
     uint32_t *st = state + size_t(g) * G.n_pos;
     const uint2 key = group_keys[g];
-    // this group's tables (and the one sign), pinned HERE: left to the compiler, the kernel arguments behind them are read where they
-    // are first used -- behind the gathers, with a wait that also holds back the table reads
-    const uint64_t tab_bits = uint64_t(uintptr_t(tabs + size_t(g) * tab_stride)), ptab_bits = uint64_t(uintptr_t(philox_tab + size_t(g) * PKU_PTAB_WORDS));
-    uint32_t pin[5] = {uint32_t(tab_bits), uint32_t(tab_bits >> 32), uint32_t(ptab_bits), uint32_t(ptab_bits >> 32), H.negmask};
-    if constexpr (!TABLE) // (with table entries the memory phase has no scalar registers to spare: there the arguments are read late)
-        asm volatile("" : "+s"(pin[0]), "+s"(pin[1]), "+s"(pin[2]), "+s"(pin[3]), "+s"(pin[4]));
-#pragma unroll
-    for (int i = 0; i < 5; i++) pin[i] = uint32_t(__builtin_amdgcn_readfirstlane(pin[i])); // (uniform: no instruction)
-    pku_const_u32 *tab = (pku_const_u32 *)uintptr_t(uint64_t(pin[1]) << 32 | pin[0]);
-    pku_const_u32 *ptab = (pku_const_u32 *)uintptr_t(uint64_t(pin[3]) << 32 | pin[2]); // this timestep's, this group's
-    PkUniHeaders Hp = H;
-    Hp.negmask = pin[4];
+    pku_const_u32 *tab = (pku_const_u32 *)(uintptr_t)(tabs + size_t(g) * tab_stride);
+    pku_const_u32 *ptab = (pku_const_u32 *)(uintptr_t)(philox_tab + size_t(g) * PKU_PTAB_WORDS); // this timestep's, this group's
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(st, 0, int(G.n_pos * sizeof(uint32_t)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t nbx_rsrc = __builtin_amdgcn_make_buffer_rsrc(st - G.n_pos, 0, -1, 0x00020000); // (pku_load)
     const __amdgpu_buffer_rsrc_t ell_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(G.nbr_ell), 0, int(uint32_t(PK_MAX_DEG) * G.n_pos * uint32_t(sizeof(uint32_t))), 0x00020000);
 
     uint32_t own[4], nb[4][PK_MAX_DEG], acc[4];
-    pku_load<D, TABLE>(st_rsrc, nbx_rsrc, ell_rsrc, Hp, G.n_pos, p0, tid & 63u, own, nb);
-    pku_decide<D, UB, PMJ>(Hp, p0, t, key, ptab, tab, own, nb, acc);
+    pku_load<D, TABLE>(st_rsrc, ell_rsrc, H, G.n_pos, p0, tid & 63u, own, nb);
+    pku_decide<D, UB, PMJ>(H, p0, t, key, ptab, tab, own, nb, acc);
 #pragma unroll
     for (int q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(own[q] ^ acc[q], st_rsrc, 4 * (p0 + 64 * q), 0, 0);
 }

@@ -88,43 +88,16 @@ __device__ __forceinline__ PhiloxShared philox_shared(uint32_t c1, uint32_t c2, 
     return PhiloxShared{uint32_t(P), uint32_t(V >> 32), uint32_t(V)};
 }
 
-// The first NV of the 14 round keys of rounds 4-10 (x of round 4, y of round 4, x of round 5, ...) in VECTOR registers: a v_bitop3
-// with a scalar source issues at half the rate of one on vector registers (tools/ubench/valu_forms.hip), and a thread that draws
-// eight calls uses every key eight times.  As many as the kernel's register budget leaves room for.
-template <int NV>
-struct PhiloxSomeVKeys {
-    uint32_t k[NV > 0 ? NV : 1];
-};
-
-template <int NV>
-__device__ __forceinline__ PhiloxSomeVKeys<NV> philox_some_vkeys(uint2 key)
-{
-    PhiloxSomeVKeys<NV> v;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const uint32_t x = i % 2 == 0 ? key.x + uint32_t(i / 2 + 3) * PHILOX_W0 : key.y + uint32_t(i / 2 + 3) * PHILOX_W1;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(v.k[i]) : "s"(x)); // (inline asm: the compiler cannot fold the scalar back into the uses)
-    }
-    return v;
-}
-
 // rounds 4-10 of the call whose uniform words are (s1, s2, s3)
-template <int NV>
-__device__ __forceinline__ uint4 philox4x32_10_late(const PhiloxShared &sh, uint32_t s1, uint32_t s2, uint32_t s3, uint2 key, const PhiloxSomeVKeys<NV> &vk)
+__device__ __forceinline__ uint4 philox4x32_10_late(const PhiloxShared &sh, uint32_t s1, uint32_t s2, uint32_t s3, uint2 key)
 {
     uint4 c = make_uint4(sh.v_hi ^ s1, sh.v_lo, sh.p_lo ^ s2, s3);
 #ifdef ISINGMC_TIMING_ONLY_CHEAP_RNG
     return c;
 #endif
+    uint2 k = make_uint2(key.x + 3u * PHILOX_W0, key.y + 3u * PHILOX_W1);
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
-        const uint64_t p0 = uint64_t(PHILOX_M0) * c.x;
-        const uint64_t p1 = uint64_t(PHILOX_M1) * c.z;
-        const uint32_t kx = 2 * r < NV ? vk.k[2 * r < NV ? 2 * r : 0] : key.x + uint32_t(r + 3) * PHILOX_W0;
-        const uint32_t ky = 2 * r + 1 < NV ? vk.k[2 * r + 1 < NV ? 2 * r + 1 : 0] : key.y + uint32_t(r + 3) * PHILOX_W1;
-        c = make_uint4(__builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c.y, kx, 0x96), uint32_t(p1),
-                       __builtin_amdgcn_bitop3_b32(uint32_t(p0 >> 32), c.w, ky, 0x96), uint32_t(p0));
-    }
+    for (int r = 3; r < 10; r++) philox_round<true>(c, k);
     return c;
 }
 
