@@ -417,6 +417,30 @@ def test_packed_uniform_degree_kernels_bit_exact(capi, oracle, monkeypatch, deg,
     _packed_case(capi, oracle, ea[1:], eb[1:], ej[1:], n, R=20, T=3, beta=0.35)
 
 
+@pytest.mark.parametrize("J", [-1.0, "glass"])
+def test_packed_uniform_degree_philox_table_across_chunks(capi, monkeypatch, J):
+    """The one-degree kernels read the wave-uniform halves of their Philox calls from a table written per chunk of 2048 timesteps
+    (pk_philox_table_kernel): ONE call of 4200 timesteps (three chunks; two group lanes forced, so that each refill has to
+    join and fork them again) equals 42 calls of 100 (a table of their own each, the size the oracle tests above pin), a
+    beta schedule included."""
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    monkeypatch.setenv("ISINGMC_PK_STREAMS", "2")
+    n = 2048
+    ea, eb, ej = _circulant(n, (1, 5, 11), 0.7)
+    if J == "glass":
+        ej = ej * np.random.default_rng(3).choice([-1.0, 1.0], len(ej))
+    g = capi.Graph(ea, eb, ej, nvars=n)
+    assert g.info.packed_degree == 6
+    betas = np.linspace(0.05, 0.6, 4200)
+    a, b = capi.States(g, capi.make_seeds(11, 96)), capi.States(g, capi.make_seeds(11, 96))
+    a.do_time_steps(4200, betas)
+    for k in range(42):
+        b.do_time_steps(100, betas[100 * k:100 * k + 100])
+    assert a.timestep == b.timestep == 4200
+    np.testing.assert_array_equal(a.states(), b.states())
+    np.testing.assert_array_equal(a.energies(), b.energies())
+
+
 def test_packed_path_equilibrium_vs_kaufman(capi, exact, monkeypatch):
     """K3 for the packed path: 32x32 torus (general path: not 64-wide), 64 replicas."""
     monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
