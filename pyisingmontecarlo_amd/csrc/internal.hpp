@@ -219,6 +219,11 @@ struct isingmc_states {
     size_t pk_bit0 = 0; // replica r of this shard is bit (r + pk_bit0) % 32 of group (r + pk_bit0) / 32 (shards cut GLOBAL groups)
     size_t pk_slots() const { return 32 * groups; } // counter slots: one per (group, bit), owned or not
     uint32_t *d_tab = nullptr; // threshold tables [groups or steps][PK_TAB_WORDS]
+    // one-degree packed kernels: the wave-uniform halves of the Philox calls of timesteps [pk_philox_t0, + pk_philox_steps) for
+    // pk_philox_groups groups (packed_types.hpp); kept across calls -- a tempering round of ten timesteps does not pay a table launch
+    uint32_t *d_pk_philox = nullptr;
+    uint64_t pk_philox_t0 = 0;
+    size_t pk_philox_steps = 0, pk_philox_groups = 0;
     bool rj = false;           // packed container on the real-coupling path (real_kernels.hpp) instead of the bit-sliced one
     RjBeta *d_rj_betas = nullptr; // per-replica acceptance scales [32 groups] (has_betas)
     unsigned long long *d_pk_slot_thr = nullptr; // on-stream tempering on the bit-sliced packed path: T_m per slot [32 groups][PK_MAX_DEG]
@@ -266,6 +271,7 @@ struct isingmc_states {
                         (void *)d_pe, (void *)d_oe, (void *)d_pm, (void *)d_om})
             if (p) (void)cached_free(p);
         if (d_tab) (void)cached_free(d_tab);
+        if (d_pk_philox) (void)cached_free(d_pk_philox);
         if (d_rj_betas) (void)cached_free(d_rj_betas);
         if (d_pk_slot_thr) (void)cached_free(d_pk_slot_thr);
         if (d_thr_mc) (void)cached_free(d_thr_mc);

@@ -417,6 +417,7 @@ static int pk_append(isingmc_states *s, uint64_t seed, const uint8_t *initial_st
         s->d_state = d_state; s->d_keys = d_keys; s->d_meas = d_meas;
         s->meas_zero = false;
         if (s->d_tab) { (void)cached_free(s->d_tab); s->d_tab = nullptr; }             // per-group tables: rebuilt by the next set_betas
+        if (s->d_pk_philox) { (void)cached_free(s->d_pk_philox); s->d_pk_philox = nullptr; s->pk_philox_steps = 0; } // rows per group count
         if (s->d_rj_betas) { (void)cached_free(s->d_rj_betas); s->d_rj_betas = nullptr; }
         hipLaunchKernelGGL(pk_init_kernel, dim3((g->pk.n_pos + 255) / 256, 1), dim3(256), 0, s->stream, s->d_state, g->pk, s->d_keys,
                            uint32_t(s->groups));
@@ -592,10 +593,14 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
         h_step_counts.resize(chunk * CS * 2);
     }
     std::vector<uint32_t> h_tabs;
-    // one-degree kernels: the wave-uniform halves of every timestep's Philox calls, written by one small launch per chunk
-    uint32_t *d_philox = nullptr;
+    // one-degree kernels: the wave-uniform halves of every timestep's Philox calls, PK_PHILOX_STEPS timesteps ahead, written by one
+    // small launch when the rows run out (s->d_pk_philox: kept across calls)
+    constexpr size_t PK_PHILOX_STEPS = 2048; // (>= chunk)
     const size_t philox_words = !s->rj && g->pk_uni_deg && !s->opt.disable_packed_uniform ? s->groups * pk_uni_philox_table_words() : 0;
-    if (philox_words) TRY(scratch.alloc(&d_philox, chunk * philox_words));
+    const auto philox_rows_ready = [&](size_t nk) {
+        return s->pk_philox_steps && s->pk_philox_groups == s->groups && s->t >= s->pk_philox_t0 &&
+               s->t + nk <= s->pk_philox_t0 + s->pk_philox_steps;
+    };
     int rc = ISINGMC_OK;
     if (device_ms) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     // The replica groups are independent: mid-size launches (a few waves per SIMD: the 64^3 glass x 64 replicas puts ONE wave on a
@@ -628,14 +633,18 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             if (s->rj) {
                 if (s->has_betas) rj_launch_timestep(s, s->d_rj_betas, 32, gb, ge, st);
                 else rj_launch_timestep(s, d_rj_steps + (beta_stride ? k : 0), 0, gb, ge, st);
-            } else if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS, d_philox + k * philox_words, gb, ge, st);
-            else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0, d_philox + k * philox_words, gb, ge, st);
+            } else {
+                const uint32_t *rows = philox_words ? s->d_pk_philox + size_t(s->t - s->pk_philox_t0) * philox_words : nullptr; // timestep s->t's
+                if (s->has_betas) pk_launch_timestep(s, s->d_tab, PK_TAB_WORDS, rows, gb, ge, st);
+                else pk_launch_timestep(s, d_step_tabs + (beta_stride ? k * PK_TAB_WORDS : 0), 0, rows, gb, ge, st);
+            }
         }
     };
     for (size_t k0 = 0; k0 < timesteps && rc == ISINGMC_OK; k0 += chunk) {
         const size_t nk = std::min(chunk, timesteps - k0);
         const bool new_step_tabs = !s->has_betas && (beta_stride || k0 == 0);
-        if (k0 > 0 && (new_step_tabs || philox_words)) { // the chunk's tables are overwritten: every lane must have finished reading them
+        const bool new_philox_rows = philox_words && !philox_rows_ready(nk);
+        if (k0 > 0 && (new_step_tabs || new_philox_rows)) { // the chunk's tables are overwritten: every lane must have finished reading them
             if (s->n_lanes > 1) TRY(lanes_join(s));
             if (new_step_tabs) HIP_TRY(hipStreamSynchronize(s->stream)); // (written from the host)
         }
@@ -651,7 +660,13 @@ static int pk_run_steps(isingmc_states *s, size_t timesteps, const double *betas
             }
             HIP_TRY(hipMemcpy(d_step_tabs, h_tabs.data(), h_tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        if (philox_words) HIP_TRY(pk_uni_launch_philox_table(s->stream, d_philox, s->d_keys, uint32_t(s->groups), s->t, uint32_t(nk)));
+        if (new_philox_rows) { // (on the main stream, the lanes joined: in order with every sweep that read the old rows)
+            if (!s->d_pk_philox) TRY(dev_alloc(&s->d_pk_philox, PK_PHILOX_STEPS * philox_words));
+            HIP_TRY(pk_uni_launch_philox_table(s->stream, s->d_pk_philox, s->d_keys, uint32_t(s->groups), s->t, uint32_t(PK_PHILOX_STEPS)));
+            s->pk_philox_t0 = s->t;
+            s->pk_philox_steps = PK_PHILOX_STEPS;
+            s->pk_philox_groups = s->groups;
+        }
         if (want_lanes > 1 && s->n_lanes <= 1) TRY(lanes_fork(s, want_lanes)); // (behind the table launch: the lanes wait for it)
         for (size_t k = 0; k < nk && rc == ISINGMC_OK; k++) {
             launch_step(k);

@@ -145,3 +145,30 @@ def test_exact_resume_from_seeds_state_and_counter(capi, exact):
     assert np.array_equal(resumed.packed(), whole.packed()) and np.array_equal(resumed.energies(), whole.energies())
     with pytest.raises(ValueError):
         resumed.timestep = 2 ** 48
+
+
+def test_packed_philox_rows_follow_the_counter(capi, exact, monkeypatch):
+    """The one-degree packed kernels keep the wave-uniform halves of their Philox calls for the next 2048 timesteps on the device
+    (isingmc_states.d_pk_philox).  Moving the counter out of that window -- forwards past it, backwards in front of it, across
+    t = 2^32 -- must rewrite the rows: every run below equals a fresh container placed at the same counter."""
+    monkeypatch.setenv("ISINGMC_FORCE_PACKED", "1")
+    ea, eb, ej = exact.cubic_lattice_edges(16, -1.0)
+    g = capi.Graph(ea, eb, ej, force_general=True)
+    assert g.info.packed_degree == 6
+    seeds = capi.make_seeds(17, 40)
+    used = capi.States(g, seeds)
+    used.do_time_steps(5, 0.25)                       # rows of timesteps [0, 2048) are on the device now
+    start = used.states()
+    for t in (3000, 100, 2040, 2 ** 32 - 3, 7):       # outside the window, back inside an older one, straddling its end, the 32-bit carry
+        used.timestep = t
+        for r in range(40):
+            used.set_state(r, start[r])
+        used.do_time_steps(12, 0.25)
+        fresh = capi.States(g, seeds)
+        fresh.timestep = t
+        for r in range(40):
+            fresh.set_state(r, start[r])
+        fresh.do_time_steps(12, 0.25)
+        assert used.timestep == fresh.timestep == t + 12
+        np.testing.assert_array_equal(used.states(), fresh.states(), err_msg=f"counter {t}")
+
