@@ -155,18 +155,18 @@ def test_packed_philox_rows_follow_the_counter(capi, exact, monkeypatch):
     ea, eb, ej = exact.cubic_lattice_edges(16, -1.0)
     g = capi.Graph(ea, eb, ej, force_general=True)
     assert g.info.packed_degree == 6
-    seeds = capi.make_seeds(17, 40)
+    seeds = capi.make_seeds(17, 64)   # whole groups: the replicas of a word share its tie stage, so every bit must be placed
     used = capi.States(g, seeds)
     used.do_time_steps(5, 0.25)                       # rows of timesteps [0, 2048) are on the device now
     start = used.states()
     for t in (3000, 100, 2040, 2 ** 32 - 3, 7):       # outside the window, back inside an older one, straddling its end, the 32-bit carry
         used.timestep = t
-        for r in range(40):
+        for r in range(64):
             used.set_state(r, start[r])
         used.do_time_steps(12, 0.25)
         fresh = capi.States(g, seeds)
         fresh.timestep = t
-        for r in range(40):
+        for r in range(64):
             fresh.set_state(r, start[r])
         fresh.do_time_steps(12, 0.25)
         assert used.timestep == fresh.timestep == t + 12
