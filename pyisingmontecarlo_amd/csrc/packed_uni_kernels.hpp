@@ -135,9 +135,11 @@ __device__ __forceinline__ void pku_resolve(const __amdgpu_buffer_rsrc_t ell_rsr
             const uint32_t hx = __builtin_amdgcn_readfirstlane(h[q][i].x);
             if (hx != PK_HDR_UNIFORM) {
                 asm volatile(""); // (a real scalar branch, skipped by nearly every slot: if-converted, each slot pays ten instructions)
-                const uint32_t e = uint32_t(int32_t(hx) >> 8);
-                if (!TABLE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e << 2 : 0u;
-                else if ((hx & 3u) == PK_HDR_UNIFORM_BUT_ONE) ent[q][i] += lane == ((hx >> 2) & 63u) ? e : 0u;
+                if constexpr (!TABLE) ent[q][i] += lane == ((hx >> 2) & 63u) ? uint32_t(int32_t(hx) >> 8) << 2 : 0u;
+                // With table entries in the launch EVERY header that is not a plain translation takes its entry from the table, the
+                // all-but-one kind too: two kinds of exception behind one branch made the compiler wait for memory (vmcnt(0)) once
+                // per exceptional slot -- 12 dependent round trips per wave on a 32^3 lattice (round 4: 13.6 -> 16.4 us per timestep
+                // on the 32^3 +-J glass until this was found; profiles/r04_small_glass_regression.txt)
                 else ent[q][i] = __builtin_amdgcn_raw_buffer_load_b32(ell_rsrc, 4 * (uint32_t(i) * n_pos + p0 + 64 * q), 0, 0);
             }
         }
