@@ -188,7 +188,7 @@ __device__ __forceinline__ uint32_t rj_index(const uint32_t (&w)[RjShape<SLOTS>:
 // depend on nothing but its own spins, beta and bit position (S7), so the bits outside are nobody's business and stay as they are.
 // The cost of a position then is ~250 vector instructions + ~21 per decided replica instead of 932.
 // HEAVY: the graph has sites that quantise at a coarser scale of their own (G.dshift; spec S7: X is shifted right by less, the
-// acceptance bound by the rest of d_p) -- one more shift per attempt; the PARTIAL instantiations always carry it.
+// acceptance bound by the rest of d_p) -- one more shift per attempt.
 template <int SLOTS, bool UB, bool PARTIAL = false, bool HEAVY = PARTIAL>
 __global__ __launch_bounds__(RjShape<SLOTS>::THREADS) void rj_sweep_kernel(uint32_t *__restrict__ state, const RjGraphDev G, const uint32_t class_begin,
                                                               const uint32_t real_end, const uint64_t t,
