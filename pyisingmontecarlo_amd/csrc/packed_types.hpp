@@ -41,7 +41,8 @@ struct PkGraphDev {
 //                 {PK_HDR_UNIFORM_BUT_ONE | lane << 2 | (e & 0xFFFFFF) << 8, 4 d} when it is that translation for every lane but
 //                 one, whose neighbour is p + d + e (-2^23 <= e < 2^23): where a row of a periodic lattice wraps around inside
 //                 the block -- on BASELINE c5's 256^3 lattice two of the 24 (block, slot) pairs of EVERY wave, which each cost a
-//                 dependent table read before the gathers could be issued (round 4: +8 %);
+//                 dependent table read before the gathers could be issued (round 4: +8 %); honoured by the table-free
+//                 instantiation only -- a launch that reads table entries anyway takes these from the table too;
 //                 else {PK_HDR_MIXED, 0}: addresses from nbr_ell;
 //   sign[B][i]  = bit l set <=> the slot-i bond of position 64 B + l has J > 0 (only read when the signs differ)
 struct PkUniHeaders {
