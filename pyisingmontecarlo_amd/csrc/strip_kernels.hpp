@@ -211,6 +211,12 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
 #pragma unroll 1
         for (uint32_t colour = 0; colour < 2; colour++) {
             const uint32_t j = 2 * k + colour; // half-sweep index of this launch
+#ifndef ISINGMC_STRIP_NO_PRIO
+            // The wait for the neighbours' rows, the update and the publication of the own boundary rows are on the chain of hand-offs
+            // between neighbouring strips; the draw of the next half-sweep's random words (half of the arithmetic) is not: the waves
+            // of a SIMD that are on the chain go first (s_setprio: -11 % per timestep at 1024^2 x 64, profiles/r04_strip_priority.txt)
+            __builtin_amdgcn_s_setprio(3);
+#endif
             // ---- halo rows of the OTHER colour as of half-sweep j - 1 (tag epoch + j), from the neighbour strips
             bool bail = false;
 #ifndef ISINGMC_STRIP_DEBUG_NOPOLL // (timing-only build, wrong results: what the waits cost)
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
             bool odd = (y_global + colour) & 1u;
             if constexpr (NW > 1) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd)) != 0; // wave-uniform: scalar branch
             uint32_t nw[4];
+
             strip_update_quad<PMJ>(lds, PL, g, colour, yl, col, Q, odd, t0 + k, key, vk, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr,
                                    jneg_uniform, R, nw, measure && colour == 1, sat, up);
             // ---- publish my boundary rows of this colour (not after the last half-sweep: nobody waits for it)
@@ -265,6 +272,9 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
                     for (int q = 0; q < 4; q++) __hip_atomic_store(dst + q, tag | nw[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+#ifndef ISINGMC_STRIP_NO_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef ISINGMC_STRIP_NO_PRECOMPUTE
             // the next half-sweep's words; in front of an exchange round they are drawn AFTER the replica's count has been
             // posted (the other strips and the partner replica wait for that post) and before the wait for the mailboxes
