@@ -255,7 +255,6 @@ __global__ __launch_bounds__(64 * NW, 4) void lat_strip_kernel(
             bool odd = (y_global + colour) & 1u;
             if constexpr (NW > 1) odd = __builtin_amdgcn_readfirstlane(uint32_t(odd)) != 0; // wave-uniform: scalar branch
             uint32_t nw[4];
-
             strip_update_quad<PMJ>(lds, PL, g, colour, yl, col, Q, odd, t0 + k, key, vk, thr, PMJ ? jneg + size_t(colour) * 4 * g.wpp : nullptr,
                                    jneg_uniform, R, nw, measure && colour == 1, sat, up);
             // ---- publish my boundary rows of this colour (not after the last half-sweep: nobody waits for it)
