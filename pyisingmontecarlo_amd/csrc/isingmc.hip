@@ -969,7 +969,7 @@ StripPlan strip_plan(const isingmc_states *s, size_t timesteps, bool ladder)
     if (mode == 0 || s->strip_disabled || g->kind != ISINGMC_KIND_LATTICE2D || !g->vec || timesteps < 2) return P;
     const uint32_t qpr = g->geom.wpr / 4;
     if ((qpr & (qpr - 1)) != 0 || qpr > 32) return P; // power of two, at least two rows per wave
-    P.nw = s->opt.strip_nw == 1 ? 1 : 4; // measured on 1024^2 x 64: 9.6 us per timestep either way; with exchange rounds 11.5 (4) / 12.0 (1)
+    P.nw = s->opt.strip_nw == 1 ? 1 : 4; // measured on 1024^2 x 64 (round 4, with wave priorities): 8.4 (4) / 8.6 (1) us per timestep; with exchange rounds 10.4 (4) / 12.0 (1)
     const uint32_t S = 64 * uint32_t(P.nw) / qpr;
     if (g->geom.H % S != 0 || g->geom.H / S < 2) return P;
     int dev_cus = 256;
